@@ -1,0 +1,46 @@
+# Builds librtamd.so (host C++ + gfx950 HIP kernels), the headless driver, and the test oracle.
+ROCM ?= /opt/rocm
+HIPCC ?= $(ROCM)/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+CS = raytrace_amd/csrc
+OUT = raytrace_amd/librtamd.so
+BUILD = build
+
+# Host code keeps every float operation unfused and in source order; the kernels get the
+# same setting so the triangle test reproduces the CPU arithmetic bit for bit, and divides
+# stay correctly rounded.
+HOSTFLAGS = -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
+HIPFLAGS = -std=c++17 -O3 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+           -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-parameter -Iinclude
+
+HOST_SRCS = obj_loader centroid_bvh raygen flatten framebuffer
+HIP_SRCS = trace_kernels capi
+HOST_OBJS = $(foreach s,$(HOST_SRCS),$(BUILD)/$(s).o)
+HIP_OBJS = $(foreach s,$(HIP_SRCS),$(BUILD)/$(s).o)
+HDRS = $(wildcard $(CS)/*.h) $(wildcard include/*.h)
+
+all: $(OUT) tools/rt_headless oracle
+
+$(BUILD)/%.o: $(CS)/%.cpp $(HDRS)
+	@mkdir -p $(BUILD)
+	$(CXX) $(HOSTFLAGS) -c $< -o $@
+
+$(BUILD)/%.o: $(CS)/%.hip $(HDRS)
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OUT): $(HOST_OBJS) $(HIP_OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -Wl,-rpath,$(ROCM)/lib -lpthread
+
+tools/rt_headless: tools/rt_headless.cpp $(OUT) $(HDRS)
+	$(CXX) -std=c++17 -O2 -Iinclude -o $@ tools/rt_headless.cpp -Lraytrace_amd -lrtamd -Wl,-rpath,'$$ORIGIN/../raytrace_amd' -Wl,-rpath,$(ROCM)/lib
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(BUILD) $(OUT) tools/rt_headless
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,153 @@
+/*
+ * rt_amd.h -- C ABI of librtamd.so: the MI355X (gfx950) closest-hit ray/scene
+ * intersection path and the host-side scene front end that feeds it.
+ *
+ * Conventions: every function returns 0 on success and a negative rt_status on
+ * failure; rt_last_error() returns the message of the calling thread's most
+ * recent failure.  Nothing aborts and no C++ exception crosses the boundary
+ * (the reference prints OpenCL error codes and carries on,
+ * core/clerrorcheck.cpp:11-18).  One rt_scene may be used by one host thread
+ * at a time; distinct scenes are independent.  Record layouts: rt_layout.h.
+ *
+ * Each entry point names the reference interface it stands in for.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include "rt_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID = -1,     /* bad argument / malformed scene */
+  RT_ERR_IO = -2,          /* file could not be read or written */
+  RT_ERR_DEVICE = -3,      /* HIP runtime error or no usable GPU */
+  RT_ERR_NOMEM = -4
+} rt_status;
+
+const char *rt_last_error(void);
+/* Number of visible HIP devices; <= 0 with rt_last_error() set if the runtime is unusable. */
+int rt_device_count(void);
+
+/* ------------------------------------------------------------------ host: scene load
+ * Stands in for LoadObj / LoadObjMaterials (core/ObjLoader.h:12-14) and MtlLib
+ * (core/MtlLib.h:23-30).  The all-zero "SKY_DEFAULT" material is inserted first, as
+ * render_client/img_main.cpp:240 does, so material 0 is the sky. */
+#define RT_LOADER_REFERENCE 0u  /* the reference tokenizer: repeated spaces produce empty tokens */
+#define RT_LOADER_TOLERANT  1u  /* empty tokens dropped; otherwise identical */
+typedef struct rt_mesh rt_mesh;
+int rt_mesh_load_obj(const char *path, unsigned loader, rt_mesh **out);
+/* Wraps caller arrays (copied).  normals/materials may be NULL with a zero count. */
+int rt_mesh_from_arrays(const rt_vec3 *verts, size_t nverts, const rt_face *faces, size_t ntris,
+                        const rt_float4 *normals, size_t nnormals, const rt_material *materials, size_t nmats,
+                        rt_mesh **out);
+size_t rt_mesh_nverts(const rt_mesh *m);
+size_t rt_mesh_ntris(const rt_mesh *m);
+size_t rt_mesh_nnormals(const rt_mesh *m);
+size_t rt_mesh_nmaterials(const rt_mesh *m);
+const rt_vec3 *rt_mesh_verts(const rt_mesh *m);
+const rt_face *rt_mesh_faces(const rt_mesh *m);
+const rt_float4 *rt_mesh_normals(const rt_mesh *m);
+const rt_material *rt_mesh_materials(const rt_mesh *m);
+/* Index of a material name, -1 if absent (does not insert). */
+int rt_mesh_material_index(const rt_mesh *m, const char *name);
+/* Loader log lines ("Quads and ngons not supported, ignoring." ...), newline-joined. */
+const char *rt_mesh_log(const rt_mesh *m);
+void rt_mesh_destroy(rt_mesh *m);
+
+/* ------------------------------------------------------------------ host: BVH build
+ * Stands in for CentroidBVHInit / CentroidBVHBuild / CentroidBVHFree
+ * (core/CentroidBVH.h:90-94).  Node array: root at 0, pre-order, 80-byte records. */
+#define RT_BVH_REFERENCE 0u  /* centroid of triangles[i]      (core/CentroidBVH.cpp:65 as written) */
+#define RT_BVH_FIXED     1u  /* centroid of triangles[set[i]] */
+typedef struct rt_bvh rt_bvh;
+int rt_bvh_build(const rt_face *faces, const rt_vec3 *verts, size_t ntris, size_t nverts, unsigned mode, rt_bvh **out);
+const rt_bvh_node *rt_bvh_nodes(const rt_bvh *b);
+size_t rt_bvh_nnodes(const rt_bvh *b);
+int rt_bvh_depth(const rt_bvh *b);       /* CentroidBVH::depth     */
+int rt_bvh_leafcount(const rt_bvh *b);   /* CentroidBVH::leafcount */
+int rt_bvh_fallback_splits(const rt_bvh *b);
+void rt_bvh_destroy(rt_bvh *b);
+
+/* ------------------------------------------------------------------ host: rays
+ * rt_primary_rays: the camera table of render_client/img_main.cpp:253-267 for a W x H
+ * image (record i + j*W), every ray starting at `origin`.
+ * rt_frame_camera: an origin on the -z side from which that pinhole frames `root`.
+ * rt_ao_rays: `count` seeded incoherent rays numbered first..first+count-1 (no reference
+ * counterpart; the divergence stress input). */
+int rt_primary_rays(int W, int H, const float origin[3], rt_ray_isect *out);
+int rt_frame_camera(const rt_aabb *root, int W, int H, float origin_out[3]);
+int rt_ao_rays(const rt_mesh *m, const rt_aabb *root, uint64_t seed, size_t first, size_t count, rt_ray_isect *out);
+
+/* ------------------------------------------------------------------ device: scene
+ * Stands in for the clCreateBuffer(COPY_HOST_PTR) uploads and static clSetKernelArg
+ * bindings of render_client/img_main.cpp:243-249,293,298-311.  Inputs are copied
+ * (the caller keeps ownership); the BVH is validated and re-flattened.  `device` is a
+ * HIP device ordinal. */
+#define RT_SCENE_WIDE2 0u   /* traverse the 64-byte two-child records  */
+#define RT_SCENE_WIDE4 4u   /* traverse the 128-byte four-child records */
+typedef struct rt_scene rt_scene;
+int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, size_t ntris,
+                    const rt_float4 *normals, size_t nnormals, const rt_material *materials, size_t nmats,
+                    const rt_bvh_node *bvh_nodes, size_t nnodes, int device, unsigned flags, rt_scene **out);
+void rt_scene_destroy(rt_scene *s);
+/* info[0..7] = {bvh2 nodes, bvh4 nodes, triangles in leaves, bvh2 depth, bvh4 depth,
+ *               bytes per bvh2 node, bytes per bvh4 node, bytes per triangle record} */
+int rt_scene_info(const rt_scene *s, uint64_t info[8]);
+/* Tuning knobs: "width" (2 or 4: which record layout the traversal walks), "persistent"
+ * (0/1: waves pull rays from a global cursor vs one ray per launched thread),
+ * "blocks_per_cu" (resident-workgroup cap of the persistent grid). */
+int rt_scene_set_param(rt_scene *s, const char *key, int value);
+
+/* ------------------------------------------------------------------ device: the hot path
+ * ray_scene_intersection: closest hit of rays[i] = (origin.xyz, direction.xyz as given)
+ * against the scene; hits[i] is a RayIntersection filled as the `trace` kernel fills its
+ * output record (render_client/tracekernel.ck:282-286 on a miss, :375-399 on a hit) plus
+ * triangle_id and t_bits.  The factoring is intersect_ray_scene of
+ * render_client/ray_scene_intersection.ckm:157-250; the launch it replaces is
+ * clEnqueueNDRangeKernel + clFinish, render_client/img_main.cpp:457-480.  rays and hits
+ * may each be host or device memory (device memory must belong to the scene's device)
+ * and must not overlap.  Returns when the hits are complete. */
+int ray_scene_intersection(const void *rays, size_t n, const rt_scene *scene, void *hits);
+
+/* Same computation, device pointers only, enqueued on `stream` (a hipStream_t; NULL =
+ * default stream) without waiting.  hits16 (optional, may be NULL) receives the compact
+ * {triangle_id, t, u, v} record; hits (optional) the 64-byte record.  At least one output. */
+int rt_intersect_async(const rt_scene *scene, const void *rays_dev, size_t n, void *hits_dev, void *hits16_dev,
+                       void *stream);
+
+/* The full `trace` kernel step (render_client/tracekernel.ck:192-414): op 0 applies the
+ * camera matrix cam[16] (row-major, rows dotted with (x,y,z,w)) to origin (w=1) and
+ * direction (w=0); op 1 reflects direction about the record's normal and nudges the
+ * origin by normal*1e-5.  Writes the output record and, if rgba is non-NULL, the RGBA32F
+ * pixel |n.d|*material.color, alpha = material.Rf ((0,0,0,0) on a miss).  Device pointers,
+ * enqueued on `stream`. */
+int rt_trace_pass(const rt_scene *scene, const void *rays_in_dev, void *rays_out_dev, float *rgba_dev, size_t n,
+                  const float cam[16], unsigned trace_operation, void *stream);
+
+/* Mean records fetched per ray by the traversal, counted on the host over rays
+ * 0, stride, 2*stride, ... : counts[0..4] = {node records, triangle records, non-empty
+ * leaves, rays that hit, rays counted}.  A measurement aid; computes no hits. */
+int rt_scene_count_fetches(const rt_scene *s, const rt_ray_isect *rays_host, size_t n, size_t stride,
+                           uint64_t counts[5]);
+/* The same counters taken on the device by an instrumented build of the kernel over all n
+ * rays (device pointer): counts[0..3] as above, counts[4] = n. */
+int rt_scene_count_fetches_device(const rt_scene *s, const void *rays_dev, size_t n, uint64_t counts[5]);
+
+/* Test hook: runs the kernel's triangle test on n independent (triangle, ray) pairs
+ * (host arrays: tri = 3 rt_vec3 per pair) and returns hit flag, t and (u,v) per pair. */
+int rt_debug_tri_batch(int device, const rt_vec3 *tri, const rt_ray *ray, size_t n, int32_t *hit, float *t, rt_vec2 *uv);
+
+/* ------------------------------------------------------------------ host: framebuffer out
+ * 32-bit BMP with the byte layout of cpu_raycast/bmp.c:6-56 (58-byte header, bottom-up
+ * rows), written in binary mode; PFM for lossless float output. */
+int rt_write_bmp32(const char *path, const uint8_t *bgra, int width, int height);
+int rt_write_pfm(const char *path, const float *rgba, int width, int height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,228 @@
+/*
+ * oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C CPU restatement of the reference's closest-hit arithmetic.  It is
+ * the checker the GPU path is compared against and the CPU baseline the
+ * benchmark times; nothing in the shipped library calls or links it.
+ *
+ * Parity pin: every function here is checked bit-for-bit against the
+ * reference's own core/ray_tri.cpp and core/raymath.cpp compiled from
+ * /root/reference into oracle/_ref (tests/test_oracle_vs_ref.py, random pairs
+ * plus edge cases) and against the one known-answer test the reference holds
+ * (cpu_raycast/raycast.cpp:12-19).
+ *
+ * Build: gcc -O2 -ffp-contract=off (no -march=native, no -ffast-math): every
+ * float operation is a single correctly-rounded IEEE-754 binary32 operation
+ * in source order, which is what the reference computes when built for x86-64.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/rt_layout.h"
+
+/* core/raydata.h:100 -- a DOUBLE literal; comparisons against it promote the
+ * float operand to double. */
+#define O_EPSILON (0.000001)
+/* core/raydata.h:129 */
+#define O_NEAR_ZERO(a) ((a) > -O_EPSILON && (a) < O_EPSILON)
+/* core/raydata.h:104-117: SUB, DOT ((x*x + y*y) + z*z, left to right), CROSS */
+#define O_SUB(a, b, o) do { (o).x = (a).x - (b).x; (o).y = (a).y - (b).y; (o).z = (a).z - (b).z; } while (0)
+#define O_DOT(a, b) ((a).x * (b).x + (a).y * (b).y + (a).z * (b).z)
+#define O_CROSS(a, b, o) do { \
+  (o).x = (a).y * (b).z - (a).z * (b).y; \
+  (o).y = (a).z * (b).x - (a).x * (b).z; \
+  (o).z = (a).x * (b).y - (a).y * (b).x; } while (0)
+
+/* core/ray_tri.cpp:6-53 -- Moller-Trumbore, two-sided, t > EPSILON. */
+int oracle_intersect_ray_triangle(const rt_vec3 *a, const rt_vec3 *b, const rt_vec3 *c,
+                                  const rt_ray *r, rt_vec2 *uvout, float *tout)
+{
+  rt_vec3 e1, e2, P, Q, T;
+  rt_vec2 uv;
+  float det, det_inv, t;
+
+  O_SUB(*b, *a, e1);
+  O_SUB(*c, *a, e2);
+  O_CROSS(r->dir, e2, P);
+
+  det = O_DOT(e1, P);
+  if (O_NEAR_ZERO(det))
+    return 0;
+
+  det_inv = 1.f / det;
+
+  O_SUB(r->origin, *a, T);
+
+  uv.u = O_DOT(T, P) * det_inv;
+  if (uv.u < 0.f || uv.u > 1.f)
+    return 0;
+
+  O_CROSS(T, e1, Q);
+
+  uv.v = O_DOT(r->dir, Q) * det_inv;
+  if (uv.v < 0.f || uv.v + uv.u > 1.f)
+    return 0;
+
+  t = O_DOT(e2, Q) * det_inv;
+  if (t > O_EPSILON) {
+    *tout = t;
+    *uvout = uv;
+    return 1;
+  }
+  return 0;
+}
+
+/* core/ray_tri.cpp:57-78 -- slab test with macro min/max (NaN-propagating
+ * the way the ternaries fall); does not report tmin. */
+#define O_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define O_MAX(a, b) ((a) > (b) ? (a) : (b))
+int oracle_intersect_ray_aabb(const rt_aabb *aabb, const rt_ray *ray)
+{
+  const float *lo = &aabb->a.x, *hi = &aabb->b.x, *o = &ray->origin.x, *d = &ray->dir.x;
+  float dir_inv[3] = { 1 / d[0], 1 / d[1], 1 / d[2] };
+  float t1 = (lo[0] - o[0]) * dir_inv[0];
+  float t2 = (hi[0] - o[0]) * dir_inv[0];
+  float tmin = O_MIN(t1, t2);
+  float tmax = O_MAX(t1, t2);
+  for (int i = 1; i < 3; ++i) {
+    t1 = (lo[i] - o[i]) * dir_inv[i];
+    t2 = (hi[i] - o[i]) * dir_inv[i];
+    tmin = O_MAX(tmin, O_MIN(t1, t2));
+    tmax = O_MIN(tmax, O_MAX(t1, t2));
+  }
+  return tmax > O_MAX(tmin, 0);
+}
+
+/* core/raymath.cpp:6-15 -- float dot, double sqrt rounded to float, float divides. */
+rt_vec3 oracle_normalize(rt_vec3 in)
+{
+  float lensq = O_DOT(in, in);
+  float len = sqrt(lensq);
+  rt_vec3 ret;
+  ret.x = in.x / len;
+  ret.y = in.y / len;
+  ret.z = in.z / len;
+  ret.w = 0.f;
+  return ret;
+}
+
+/* render_client/img_main.cpp:253-267 generalised from IMG_X x IMG_Y to W x H.
+ * The reference indexes [i + j*IMG_Y], identical to [i + j*W] for its square
+ * image; W is used here so rows do not overlap when W != H.  `origin` replaces
+ * the constant (0,0,-5,1). */
+void oracle_primary_rays(int W, int H, const float origin[3], rt_ray_isect *out)
+{
+  rt_vec3 o = { W / 2.f, H / 2.f, (float)(-5 * W), 0.f };
+  for (int i = 0; i < W; ++i) {
+    for (int j = 0; j < H; ++j) {
+      rt_vec3 end = { (float)i, (float)j, 0.f, 0.f }, d;
+      O_SUB(end, o, d);
+      d.w = 0.f;
+      d = oracle_normalize(d);
+      rt_ray_isect *r = &out[(size_t)i + (size_t)j * W];
+      memset(r, 0, sizeof *r);
+      r->direction.x = d.x; r->direction.y = d.y; r->direction.z = d.z; r->direction.w = 0.f;
+      r->origin.x = origin[0]; r->origin.y = origin[1]; r->origin.z = origin[2]; r->origin.w = 1.f;
+      r->normal.x = 0.f; r->normal.y = 0.f; r->normal.z = 1.f; r->normal.w = 0.f;
+      r->triangle_id = 0xFFFFFFFFu;
+    }
+  }
+}
+
+/* Brute-force closest hit, the loop shape of cpu_raycast/raycast.cpp:113-122:
+ * every triangle in index order, strict `dist < closest`, so the LOWEST index
+ * wins an exact tie.  closest starts at FLT_MAX (the kernel's MAXFLOAT,
+ * render_client/tracekernel.ck:278) rather than main2's 99999.
+ *
+ * Also records the second-smallest t over all OTHER triangles so callers can
+ * count near-tie rays (|t2 - t1| <= eps * t1). */
+typedef struct {
+  const rt_vec3 *verts; const rt_face *faces; size_t ntris;
+  const rt_ray_isect *rays; size_t begin, end;
+  rt_hit16 *hits; float *second_t;
+} bf_job;
+
+static void *bf_worker(void *arg)
+{
+  bf_job *j = (bf_job *)arg;
+  for (size_t k = j->begin; k < j->end; ++k) {
+    rt_ray ray;
+    ray.origin.x = j->rays[k].origin.x; ray.origin.y = j->rays[k].origin.y; ray.origin.z = j->rays[k].origin.z; ray.origin.w = 0.f;
+    ray.dir.x = j->rays[k].direction.x; ray.dir.y = j->rays[k].direction.y; ray.dir.z = j->rays[k].direction.z; ray.dir.w = 0.f;
+    float closest = 3.402823466e+38f, second = 3.402823466e+38f;
+    rt_hit16 h = { RT_MISS_ID, closest, 0.f, 0.f };
+    for (size_t mi = 0; mi < j->ntris; ++mi) {
+      const uint32_t *s = j->faces[mi].s;
+      rt_vec2 uv; float dist;
+      if (oracle_intersect_ray_triangle(&j->verts[s[0]], &j->verts[s[1]], &j->verts[s[2]], &ray, &uv, &dist)) {
+        if (dist < closest) {
+          second = closest;
+          closest = dist; h.triangle_id = (uint32_t)mi; h.t = dist; h.u = uv.u; h.v = uv.v;
+        } else if (dist < second) {
+          second = dist;
+        }
+      }
+    }
+    j->hits[k] = h;
+    if (j->second_t) j->second_t[k] = second;
+  }
+  return NULL;
+}
+
+/* hits[k] = closest hit of rays[k] (origin.xyz, direction.xyz used as given;
+ * no camera matrix).  second_t may be NULL.  nthreads <= 0 -> 1. */
+int oracle_closest_hit(const rt_vec3 *verts, const rt_face *faces, size_t ntris,
+                       const rt_ray_isect *rays, size_t nrays,
+                       rt_hit16 *hits, float *second_t, int nthreads)
+{
+  if (nthreads <= 0) nthreads = 1;
+  if ((size_t)nthreads > nrays) nthreads = nrays ? (int)nrays : 1;
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+  bf_job *jobs = (bf_job *)malloc(sizeof(bf_job) * nthreads);
+  if (!th || !jobs) { free(th); free(jobs); return -1; }
+  for (int i = 0; i < nthreads; ++i) {
+    bf_job jb = { verts, faces, ntris, rays, nrays * i / nthreads, nrays * (i + 1) / nthreads, hits, second_t };
+    jobs[i] = jb;
+    if (i > 0) pthread_create(&th[i], NULL, bf_worker, &jobs[i]);
+  }
+  bf_worker(&jobs[0]);
+  for (int i = 1; i < nthreads; ++i) pthread_join(th[i], NULL);
+  free(th); free(jobs);
+  return 0;
+}
+
+/* Batch form of the single test, for the bit-equality sweeps:
+ * tri[i] = 3 x rt_vec3, ray[i]; out_hit[i], out_t[i], out_uv[i]. */
+void oracle_tri_batch(const rt_vec3 *tri, const rt_ray *ray, size_t n, int32_t *out_hit, float *out_t, rt_vec2 *out_uv)
+{
+  for (size_t i = 0; i < n; ++i) {
+    float t = -1.f; rt_vec2 uv = { 0.f, 0.f };
+    out_hit[i] = oracle_intersect_ray_triangle(&tri[3 * i], &tri[3 * i + 1], &tri[3 * i + 2], &ray[i], &uv, &t);
+    out_t[i] = t; out_uv[i] = uv;
+  }
+}
+
+void oracle_aabb_batch(const rt_aabb *bb, const rt_ray *ray, size_t n, int32_t *out_hit)
+{
+  for (size_t i = 0; i < n; ++i) out_hit[i] = oracle_intersect_ray_aabb(&bb[i], &ray[i]);
+}
+
+/* Op-1 ray regeneration, render_client/tracekernel.ck:101-104,227-233, in
+ * left-to-right unfused float arithmetic: dir = v - (2*dot4(v,n))*n with a
+ * 4-component dot, origin += n * 0.00001f.  OpenCL leaves the rounding of its
+ * dot() builtin to the implementation, so this ordering is the definition the
+ * GPU path is held to, not a reference-pinned one. */
+void oracle_reflect_ray(const rt_ray_isect *in, rt_ray *out)
+{
+  const rt_float4 v = in->direction, n = in->normal;
+  float d = v.x * n.x + v.y * n.y + v.z * n.z + v.w * n.w;
+  float s = 2.0f * d;
+  out->dir.x = v.x - s * n.x; out->dir.y = v.y - s * n.y; out->dir.z = v.z - s * n.z; out->dir.w = 0.f;
+  out->origin.x = in->origin.x + n.x * 0.00001f;
+  out->origin.y = in->origin.y + n.y * 0.00001f;
+  out->origin.z = in->origin.z + n.z * 0.00001f;
+  out->origin.w = 0.f;
+}

@@ -1,0 +1,61 @@
+/*
+ * ref_shim.cpp -- TEST INFRASTRUCTURE.  extern "C" doorways onto the
+ * reference's own functions so Python (ctypes) can call them.  It contains no
+ * algorithm: every call forwards to code compiled from /root/reference/core
+ * (see Makefile).  Built only where /root/reference exists; the product never
+ * links it.
+ */
+#include "raydata.h"
+#include "ray_tri.h"
+#include "GeomUtil.h"
+#include "CentroidBVH.h"
+#include "MtlLib.h"
+#include <cstring>
+#include <cstddef>
+
+static_assert(sizeof(vec3) == 16 && sizeof(Ray) == 32 && sizeof(RayIntersection) == 64, "layout");
+static_assert(sizeof(CentroidBVHNode) == 80 && sizeof(Material) == 48 && sizeof(cl_uint8) == 32, "layout");
+
+extern "C" {
+
+int ref_intersect_ray_triangle(const vec3 *a, const vec3 *b, const vec3 *c, const Ray *r, vec2 *uv, float *t)
+{ return intersect_ray_triangle(a, b, c, r, uv, t); }
+
+int ref_intersect_ray_aabb(const AABB *bb, const Ray *r)
+{ float t = 0; return intersect_ray_aabb(bb, r, &t); }
+
+void ref_tri_batch(const vec3 *tri, const Ray *ray, size_t n, int *out_hit, float *out_t, vec2 *out_uv)
+{
+  for (size_t i = 0; i < n; ++i) {
+    float t = -1.f; vec2 uv = { 0.f, 0.f };
+    out_hit[i] = intersect_ray_triangle(&tri[3 * i], &tri[3 * i + 1], &tri[3 * i + 2], &ray[i], &uv, &t);
+    out_t[i] = t; out_uv[i] = uv;
+  }
+}
+
+void ref_aabb_batch(const AABB *bb, const Ray *ray, size_t n, int *out_hit)
+{ for (size_t i = 0; i < n; ++i) { float t = 0; out_hit[i] = intersect_ray_aabb(&bb[i], &ray[i], &t); } }
+
+void ref_normalize(const vec3 *in, vec3 *out) { *out = normalize(*in); }
+
+/* Builds with the reference's CentroidBVHBuild and copies the node array out
+ * (nodes may be NULL to query the count).  Returns the node count; stats =
+ * {depth, tricount, leafcount}. */
+size_t ref_bvh_build(const cl_uint8 *tris, const vec3 *verts, size_t ntris, size_t nverts,
+                     CentroidBVHNode *nodes, size_t capacity, int *stats)
+{
+  CentroidBVH bvh;
+  CentroidBVHInit(&bvh);
+  CentroidBVHBuild(&bvh, tris, verts, ntris, nverts);
+  size_t n = bvh.listSize;
+  if (nodes && n <= capacity) std::memcpy(nodes, bvh.nodeList, n * sizeof(CentroidBVHNode));
+  if (stats) { stats[0] = bvh.depth; stats[1] = bvh.tricount; stats[2] = bvh.leafcount; }
+  CentroidBVHFree(&bvh);
+  return n;
+}
+
+void ref_min_size_aabb(AABB *bb) { MinSizeAABB(bb); }
+void ref_centroid(const vec3 *tri3, vec3 *c) { Centroid(reinterpret_cast<Tri const *>(tri3), c); }
+int ref_point_in_aabb(const vec3 *p, const AABB *bb) { return PointInAABB(p, bb) ? 1 : 0; }
+
+}

@@ -1,0 +1,314 @@
+"""raytrace_amd -- Python face of librtamd.so, the MI355X closest-hit ray/scene path.
+
+This module holds no algorithm.  It binds the C ABI of ``include/rt_amd.h`` with ctypes
+and mirrors, for the parity tests and the benchmark, the host-side calling sequence of the
+reference's ``cl_init``/``cl_update`` (render_client/img_main.cpp:120-316, :437-507):
+load a mesh, build the BVH, create the device scene, trace ray records.
+
+The shared library must have been built (``make`` or ``__graft_entry__.build()``); if it
+is missing, importing this package raises -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtamd.so")
+REPO_ROOT = os.path.dirname(_HERE)
+MODELS_DIR = os.path.join(REPO_ROOT, "assets", "models")
+
+RAY_FLOATS = 16          # one 64-byte RayIntersection record = 16 x 4 bytes
+MISS_ID = 0xFFFFFFFF
+LOADER = {"reference": 0, "tolerant": 1}
+BVH_MODE = {"reference": 0, "fixed": 1}
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def _preload_hip_runtime():
+    """Make sure the process ends up with ONE HIP runtime.
+
+    PyTorch's ROCm wheel ships its own libamdhip64.so (same SONAME as the system one).  If
+    this library bound the system copy first and torch were imported later, the process
+    would hold two runtimes and device pointers could not be shared.  When torch is
+    installed but not yet imported, its copy is loaded first so both sides bind it.
+    """
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()); "
+            "raytrace_amd has no fallback implementation")
+    _preload_hip_runtime()
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, u32, u64, i32 = C.c_void_p, C.c_size_t, C.c_uint, C.c_uint64, C.c_int
+    sig = {
+        "rt_last_error": (C.c_char_p, []),
+        "rt_device_count": (i32, []),
+        "rt_mesh_load_obj": (i32, [C.c_char_p, u32, C.POINTER(vp)]),
+        "rt_mesh_from_arrays": (i32, [vp, sz, vp, sz, vp, sz, vp, sz, C.POINTER(vp)]),
+        "rt_mesh_nverts": (sz, [vp]), "rt_mesh_ntris": (sz, [vp]),
+        "rt_mesh_nnormals": (sz, [vp]), "rt_mesh_nmaterials": (sz, [vp]),
+        "rt_mesh_verts": (vp, [vp]), "rt_mesh_faces": (vp, [vp]),
+        "rt_mesh_normals": (vp, [vp]), "rt_mesh_materials": (vp, [vp]),
+        "rt_mesh_material_index": (i32, [vp, C.c_char_p]),
+        "rt_mesh_log": (C.c_char_p, [vp]),
+        "rt_mesh_destroy": (None, [vp]),
+        "rt_bvh_build": (i32, [vp, vp, sz, sz, u32, C.POINTER(vp)]),
+        "rt_bvh_nodes": (vp, [vp]), "rt_bvh_nnodes": (sz, [vp]),
+        "rt_bvh_depth": (i32, [vp]), "rt_bvh_leafcount": (i32, [vp]),
+        "rt_bvh_fallback_splits": (i32, [vp]),
+        "rt_bvh_destroy": (None, [vp]),
+        "rt_primary_rays": (i32, [i32, i32, C.POINTER(C.c_float), vp]),
+        "rt_frame_camera": (i32, [vp, i32, i32, C.POINTER(C.c_float)]),
+        "rt_ao_rays": (i32, [vp, vp, u64, sz, sz, vp]),
+        "rt_scene_create": (i32, [vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, i32, u32, C.POINTER(vp)]),
+        "rt_scene_destroy": (None, [vp]),
+        "rt_scene_info": (i32, [vp, C.POINTER(u64)]),
+        "rt_scene_set_param": (i32, [vp, C.c_char_p, i32]),
+        "ray_scene_intersection": (i32, [vp, sz, vp, vp]),
+        "rt_intersect_async": (i32, [vp, vp, sz, vp, vp, vp]),
+        "rt_trace_pass": (i32, [vp, vp, vp, vp, sz, C.POINTER(C.c_float), u32, vp]),
+        "rt_scene_count_fetches": (i32, [vp, vp, sz, sz, C.POINTER(u64)]),
+        "rt_scene_count_fetches_device": (i32, [vp, vp, sz, C.POINTER(u64)]),
+        "rt_debug_tri_batch": (i32, [i32, vp, vp, sz, vp, vp, vp]),
+        "rt_write_bmp32": (i32, [C.c_char_p, vp, i32, i32]),
+        "rt_write_pfm": (i32, [C.c_char_p, vp, i32, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here means the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(f"rt error {rc}: {lib.rt_last_error().decode(errors='replace')}")
+
+
+def _ptr(a):
+    """Address of a numpy array's buffer, or a raw integer device address, or None."""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.c_void_p(int(a))
+    return C.c_void_p(a.ctypes.data)
+
+
+def _copy(ptr, count, width, dtype):
+    if not ptr or count == 0:
+        return np.zeros((0, width), dtype=dtype)
+    raw = (C.c_char * (count * width * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(raw, dtype=dtype).reshape(count, width).copy()
+
+
+class Mesh:
+    """Vertices (n,4) f32, faces (n,8) u32 {v0,v1,v2,mat,n0,n1,n2,0}, normals (n,4) f32,
+    materials (n,12) f32-view of the 48-byte records.  core/ObjLoader.h:12-14."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.verts = _copy(lib.rt_mesh_verts(handle), lib.rt_mesh_nverts(handle), 4, np.float32)
+        self.faces = _copy(lib.rt_mesh_faces(handle), lib.rt_mesh_ntris(handle), 8, np.uint32)
+        self.normals = _copy(lib.rt_mesh_normals(handle), lib.rt_mesh_nnormals(handle), 4, np.float32)
+        self.materials = _copy(lib.rt_mesh_materials(handle), lib.rt_mesh_nmaterials(handle), 12, np.float32)
+        self.log = lib.rt_mesh_log(handle).decode(errors="replace").splitlines()
+
+    @classmethod
+    def load_obj(cls, path, loader="tolerant"):
+        h = C.c_void_p()
+        _check(lib.rt_mesh_load_obj(os.fsencode(path), LOADER[loader], C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, verts, faces, normals=None, materials=None):
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 4)
+        faces = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 8)
+        normals = np.zeros((0, 4), np.float32) if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 4)
+        materials = np.zeros((0, 12), np.float32) if materials is None else np.ascontiguousarray(materials, np.float32).reshape(-1, 12)
+        h = C.c_void_p()
+        _check(lib.rt_mesh_from_arrays(_ptr(verts), len(verts), _ptr(faces), len(faces),
+                                       _ptr(normals) if len(normals) else None, len(normals),
+                                       _ptr(materials) if len(materials) else None, len(materials), C.byref(h)))
+        return cls(h)
+
+    def material_index(self, name):
+        return lib.rt_mesh_material_index(self._h, name.encode())
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.rt_mesh_destroy(h)
+
+
+class BVH:
+    """The 80-byte CentroidBVHNode array (n,20) u32-view.  core/CentroidBVH.h:90-94."""
+
+    def __init__(self, mesh, mode="fixed"):
+        h = C.c_void_p()
+        _check(lib.rt_bvh_build(_ptr(mesh.faces), _ptr(mesh.verts), len(mesh.faces), len(mesh.verts),
+                                BVH_MODE[mode], C.byref(h)))
+        self._h = h
+        self.nodes = _copy(lib.rt_bvh_nodes(h), lib.rt_bvh_nnodes(h), 20, np.uint32)
+        self.depth = lib.rt_bvh_depth(h)
+        self.leafcount = lib.rt_bvh_leafcount(h)
+        self.fallback_splits = lib.rt_bvh_fallback_splits(h)
+
+    @property
+    def root_box(self):
+        """(2,4) f32: the root AABB min and max rows."""
+        return self.nodes[0, 8:16].view(np.float32).reshape(2, 4).copy()
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.rt_bvh_destroy(h)
+
+
+def primary_rays(width, height, origin):
+    """Camera ray table of render_client/img_main.cpp:253-267 as an (W*H, 16) f32 array."""
+    out = np.zeros((width * height, RAY_FLOATS), dtype=np.float32)
+    o = (C.c_float * 3)(*[float(x) for x in origin])
+    _check(lib.rt_primary_rays(width, height, o, _ptr(out)))
+    return out
+
+
+def frame_camera(root_box, width, height):
+    box = np.ascontiguousarray(root_box, dtype=np.float32).reshape(2, 4)
+    o = (C.c_float * 3)()
+    _check(lib.rt_frame_camera(_ptr(box), width, height, o))
+    return np.array([o[0], o[1], o[2]], dtype=np.float32)
+
+
+def ao_rays(mesh, root_box, seed, first, count):
+    out = np.zeros((count, RAY_FLOATS), dtype=np.float32)
+    box = np.ascontiguousarray(root_box, dtype=np.float32).reshape(2, 4)
+    _check(lib.rt_ao_rays(mesh._h, _ptr(box), seed, first, count, _ptr(out)))
+    return out
+
+
+def hit_fields(hits):
+    """Splits (n,16) f32 hit records into (triangle_id u32, t f32, u f32, v f32)."""
+    ids = hits[:, 14].view(np.uint32)
+    t = hits[:, 15]
+    return ids.copy(), t.copy(), hits[:, 12].copy(), hits[:, 13].copy()
+
+
+class Scene:
+    """Device-resident scene.  Stands in for the buffer uploads and static kernel-argument
+    bindings of render_client/img_main.cpp:243-249,293,298-311."""
+
+    def __init__(self, mesh, bvh, device=0, width=2):
+        h = C.c_void_p()
+        nodes = np.ascontiguousarray(bvh.nodes if isinstance(bvh, BVH) else bvh, dtype=np.uint32).reshape(-1, 20)
+        _check(lib.rt_scene_create(_ptr(mesh.verts), len(mesh.verts), _ptr(mesh.faces), len(mesh.faces),
+                                   _ptr(mesh.normals) if len(mesh.normals) else None, len(mesh.normals),
+                                   _ptr(mesh.materials) if len(mesh.materials) else None, len(mesh.materials),
+                                   _ptr(nodes), len(nodes), device, 4 if width == 4 else 0, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def info(self):
+        v = (C.c_uint64 * 8)()
+        _check(lib.rt_scene_info(self._h, v))
+        keys = ["nodes2", "nodes4", "leaf_tris", "depth2", "depth4", "node2_bytes", "node4_bytes", "tri_bytes"]
+        return dict(zip(keys, [int(x) for x in v]))
+
+    def set_param(self, key, value):
+        _check(lib.rt_scene_set_param(self._h, key.encode(), int(value)))
+
+    def intersect(self, rays):
+        """ray_scene_intersection on host arrays: (n,16) f32 rays -> (n,16) f32 hit records."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, RAY_FLOATS)
+        hits = np.empty_like(rays)
+        _check(lib.ray_scene_intersection(_ptr(rays), len(rays), self._h, _ptr(hits)))
+        return hits
+
+    def intersect_device(self, rays_ptr, n, hits_ptr):
+        """ray_scene_intersection on raw device addresses (synchronous)."""
+        _check(lib.ray_scene_intersection(_ptr(rays_ptr), n, self._h, _ptr(hits_ptr)))
+
+    def intersect_async(self, rays_ptr, n, hits_ptr=None, hits16_ptr=None, stream=0):
+        _check(lib.rt_intersect_async(self._h, _ptr(rays_ptr), n, _ptr(hits_ptr), _ptr(hits16_ptr),
+                                      C.c_void_p(stream) if stream else None))
+
+    def trace_pass(self, rays_in_ptr, rays_out_ptr, rgba_ptr, n, cam, op, stream=0):
+        cam_arr = (C.c_float * 16)(*[float(x) for x in np.asarray(cam, dtype=np.float32).reshape(16)])
+        _check(lib.rt_trace_pass(self._h, _ptr(rays_in_ptr), _ptr(rays_out_ptr), _ptr(rgba_ptr), n, cam_arr, op,
+                                 C.c_void_p(stream) if stream else None))
+
+    def count_fetches(self, rays, stride=1):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, RAY_FLOATS)
+        v = (C.c_uint64 * 5)()
+        _check(lib.rt_scene_count_fetches(self._h, _ptr(rays), len(rays), stride, v))
+        return dict(zip(["nodes", "tris", "leaves", "rays_hit", "rays"], [int(x) for x in v]))
+
+    def count_fetches_device(self, rays_ptr, n):
+        v = (C.c_uint64 * 5)()
+        _check(lib.rt_scene_count_fetches_device(self._h, _ptr(rays_ptr), n, v))
+        return dict(zip(["nodes", "tris", "leaves", "rays_hit", "rays"], [int(x) for x in v]))
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.rt_scene_destroy(h)
+
+    def __del__(self):
+        self.close()
+
+
+def debug_tri_batch(tri, ray, device=0):
+    """Runs the kernel's triangle test on n (triangle, ray) pairs: tri (n,3,4) f32, ray (n,8) f32."""
+    tri = np.ascontiguousarray(tri, dtype=np.float32).reshape(-1, 3, 4)
+    ray = np.ascontiguousarray(ray, dtype=np.float32).reshape(-1, 8)
+    n = len(ray)
+    hit = np.zeros(n, np.int32)
+    t = np.zeros(n, np.float32)
+    uv = np.zeros((n, 2), np.float32)
+    _check(lib.rt_debug_tri_batch(device, _ptr(tri), _ptr(ray), n, _ptr(hit), _ptr(t), _ptr(uv)))
+    return hit, t, uv
+
+
+def write_bmp32(path, bgra):
+    bgra = np.ascontiguousarray(bgra, dtype=np.uint8)
+    h, w = bgra.shape[0], bgra.shape[1]
+    _check(lib.rt_write_bmp32(os.fsencode(path), _ptr(bgra), w, h))
+
+
+def write_pfm(path, rgba):
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    h, w = rgba.shape[0], rgba.shape[1]
+    _check(lib.rt_write_pfm(os.fsencode(path), _ptr(rgba), w, h))
+
+
+def load_scene(model, loader="tolerant", bvh_mode="fixed", device=0, width=2):
+    """Convenience: mesh + BVH + device scene for a model under assets/models."""
+    path = model if os.path.exists(model) else os.path.join(MODELS_DIR, model)
+    mesh = Mesh.load_obj(path, loader)
+    bvh = BVH(mesh, bvh_mode)
+    return mesh, bvh, Scene(mesh, bvh, device=device, width=width)

@@ -1,0 +1,542 @@
+// capi.hip -- implementation of the C ABI declared in include/rt_amd.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "device_scene.h"
+#include "host_scene.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int Fail(rt_status code, const std::string &msg)
+{
+  g_error = msg;
+  return code;
+}
+
+int FailHip(hipError_t e, const char *what)
+{
+  return Fail(RT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define RT_HIP(call)                                   \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) return FailHip(e_, #call);   \
+  } while (0)
+
+// Makes `device` current for the scope and restores the caller's device afterwards.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int device)
+  {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard()
+  {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+template <typename T>
+int Upload(T **dst, const void *src, size_t bytes)
+{
+  *dst = nullptr;
+  if (bytes == 0) bytes = 16;  // keep every pointer valid
+  void *p = nullptr;
+  RT_HIP(hipMalloc(&p, bytes));
+  *dst = static_cast<T *>(p);
+  if (src) RT_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+  else RT_HIP(hipMemset(p, 0, bytes));
+  return RT_OK;
+}
+
+constexpr int kCounterSlots = 64;        // ray cursors, one 128-byte line each, used round-robin
+constexpr int kCounterStride = 32;       // uint32 per slot
+
+}  // namespace
+
+struct rt_mesh {
+  rt::Mesh mesh;
+  std::string log_joined;
+};
+
+struct rt_bvh {
+  rt::CentroidBVH bvh;
+};
+
+struct rt_scene {
+  int device = 0;
+  int num_cu = 256;
+  int width = 2;
+  int persistent = 1;
+  int blocks_per_cu = 8;
+  rt::FlatScene flat;          // host copy (fetch counting, info)
+  size_t nverts = 0, ntris = 0, nnormals = 0, nmats = 0;
+  float4 *d_nodes2 = nullptr, *d_nodes4 = nullptr, *d_tris = nullptr;
+  rt_vec3 *d_verts = nullptr;
+  rt_face *d_faces = nullptr;
+  rt_float4 *d_normals = nullptr;
+  rt_material *d_mats = nullptr;
+  uint32_t *d_counters = nullptr;
+  unsigned long long *d_stats = nullptr;
+  mutable int next_counter = 0;
+  // staging for host-pointer calls
+  mutable void *d_stage_in = nullptr, *d_stage_out = nullptr;
+  mutable size_t stage_in_bytes = 0, stage_out_bytes = 0;
+};
+
+namespace {
+
+void FillArgs(const rt_scene *s, rt::KernelArgs &a)
+{
+  std::memset(&a, 0, sizeof a);
+  a.nodes = s->width == 4 ? s->d_nodes4 : s->d_nodes2;
+  a.tris = s->d_tris;
+  a.verts = s->d_verts;
+  a.faces = s->d_faces;
+  a.normals = s->d_normals;
+  a.mats = s->d_mats;
+  a.nnormals = static_cast<uint32_t>(s->nnormals);
+  a.nmats = static_cast<uint32_t>(s->nmats);
+  a.stack_entries = static_cast<uint32_t>(s->width == 4 ? s->flat.stack4 : s->flat.stack2);
+  a.scale = s->flat.scale;
+  a.stats = s->d_stats;
+}
+
+// Enqueues one launch over at most 2^30 rays.
+int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStream_t stream)
+{
+  const uint32_t blocks_needed = (a.n + 255u) / 256u;
+  const bool persistent = s->persistent && !count;
+  uint32_t grid = blocks_needed;
+  if (persistent) {
+    const uint32_t cap = static_cast<uint32_t>(s->num_cu) * static_cast<uint32_t>(s->blocks_per_cu);
+    if (grid > cap) grid = cap;
+    const int slot = s->next_counter;
+    s->next_counter = (slot + 1) % kCounterSlots;
+    a.counter = s->d_counters + slot * kCounterStride;
+    RT_HIP(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream));
+  }
+  if (static_cast<size_t>(a.stack_entries) * 1024u > 160u * 1024u)
+    return Fail(RT_ERR_INVALID, "bvh too deep for the LDS traversal stack");
+  RT_HIP(rt::LaunchClosestHit(a, s->width, mode, persistent, count, grid, stream));
+  return RT_OK;
+}
+
+constexpr size_t kChunk = size_t(1) << 30;
+
+bool IsDevicePointer(const void *p)
+{
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // unregistered host memory reports an error; clear it
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int EnsureStage(void **buf, size_t *have, size_t want)
+{
+  if (*have >= want) return RT_OK;
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr;
+  *have = 0;
+  RT_HIP(hipMalloc(buf, want));
+  *have = want;
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_error.c_str(); }
+
+int rt_device_count(void)
+{
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    FailHip(e, "hipGetDeviceCount");
+    return 0;
+  }
+  return n;
+}
+
+// ---------------------------------------------------------------- mesh
+int rt_mesh_load_obj(const char *path, unsigned loader, rt_mesh **out)
+{
+  if (!path || !out) return Fail(RT_ERR_INVALID, "null argument");
+  if (loader > RT_LOADER_TOLERANT) return Fail(RT_ERR_INVALID, "unknown loader mode");
+  rt_mesh *m = new (std::nothrow) rt_mesh;
+  if (!m) return Fail(RT_ERR_NOMEM, "out of memory");
+  try {
+    if (!rt::LoadObjFile(path, m->mesh, static_cast<rt::LoaderMode>(loader))) {
+      delete m;
+      return Fail(RT_ERR_IO, std::string("cannot open ") + path);
+    }
+  } catch (const std::exception &ex) {
+    delete m;
+    return Fail(RT_ERR_INVALID, std::string("obj load failed: ") + ex.what());
+  }
+  *out = m;
+  return RT_OK;
+}
+
+int rt_mesh_from_arrays(const rt_vec3 *verts, size_t nverts, const rt_face *faces, size_t ntris,
+                        const rt_float4 *normals, size_t nnormals, const rt_material *materials, size_t nmats,
+                        rt_mesh **out)
+{
+  if (!out || (!verts && nverts) || (!faces && ntris) || (!normals && nnormals) || (!materials && nmats))
+    return Fail(RT_ERR_INVALID, "null argument");
+  rt_mesh *m = new (std::nothrow) rt_mesh;
+  if (!m) return Fail(RT_ERR_NOMEM, "out of memory");
+  m->mesh.verts.assign(verts, verts + nverts);
+  m->mesh.faces.assign(faces, faces + ntris);
+  if (nnormals) m->mesh.normals.assign(normals, normals + nnormals);
+  if (nmats) m->mesh.mtllib.materials.assign(materials, materials + nmats);
+  *out = m;
+  return RT_OK;
+}
+
+size_t rt_mesh_nverts(const rt_mesh *m) { return m ? m->mesh.verts.size() : 0; }
+size_t rt_mesh_ntris(const rt_mesh *m) { return m ? m->mesh.faces.size() : 0; }
+size_t rt_mesh_nnormals(const rt_mesh *m) { return m ? m->mesh.normals.size() : 0; }
+size_t rt_mesh_nmaterials(const rt_mesh *m) { return m ? m->mesh.mtllib.materials.size() : 0; }
+const rt_vec3 *rt_mesh_verts(const rt_mesh *m) { return m ? m->mesh.verts.data() : nullptr; }
+const rt_face *rt_mesh_faces(const rt_mesh *m) { return m ? m->mesh.faces.data() : nullptr; }
+const rt_float4 *rt_mesh_normals(const rt_mesh *m) { return m ? m->mesh.normals.data() : nullptr; }
+const rt_material *rt_mesh_materials(const rt_mesh *m) { return m ? m->mesh.mtllib.materials.data() : nullptr; }
+
+int rt_mesh_material_index(const rt_mesh *m, const char *name)
+{
+  if (!m || !name) return -1;
+  auto it = m->mesh.mtllib.indices.find(name);
+  return it == m->mesh.mtllib.indices.end() ? -1 : it->second;
+}
+
+const char *rt_mesh_log(const rt_mesh *m)
+{
+  if (!m) return "";
+  rt_mesh *mm = const_cast<rt_mesh *>(m);
+  mm->log_joined.clear();
+  for (auto const &l : m->mesh.log) {
+    mm->log_joined += l;
+    mm->log_joined += '\n';
+  }
+  return mm->log_joined.c_str();
+}
+
+void rt_mesh_destroy(rt_mesh *m) { delete m; }
+
+// ---------------------------------------------------------------- bvh
+int rt_bvh_build(const rt_face *faces, const rt_vec3 *verts, size_t ntris, size_t nverts, unsigned mode, rt_bvh **out)
+{
+  if (!out || !faces || !verts) return Fail(RT_ERR_INVALID, "null argument");
+  if (mode > RT_BVH_FIXED) return Fail(RT_ERR_INVALID, "unknown bvh mode");
+  if (ntris == 0 || nverts == 0) return Fail(RT_ERR_INVALID, "bvh build needs at least one triangle");
+  for (size_t i = 0; i < ntris; ++i)
+    if (faces[i].s[0] >= nverts || faces[i].s[1] >= nverts || faces[i].s[2] >= nverts)
+      return Fail(RT_ERR_INVALID, "face vertex index out of range");
+  rt_bvh *b = new (std::nothrow) rt_bvh;
+  if (!b) return Fail(RT_ERR_NOMEM, "out of memory");
+  try {
+    rt::CentroidBVHBuild(&b->bvh, faces, verts, ntris, nverts, static_cast<rt::BvhMode>(mode));
+  } catch (const std::exception &ex) {
+    delete b;
+    return Fail(RT_ERR_NOMEM, std::string("bvh build failed: ") + ex.what());
+  }
+  *out = b;
+  return RT_OK;
+}
+
+const rt_bvh_node *rt_bvh_nodes(const rt_bvh *b) { return b ? b->bvh.nodes.data() : nullptr; }
+size_t rt_bvh_nnodes(const rt_bvh *b) { return b ? b->bvh.nodes.size() : 0; }
+int rt_bvh_depth(const rt_bvh *b) { return b ? b->bvh.depth : 0; }
+int rt_bvh_leafcount(const rt_bvh *b) { return b ? b->bvh.leafcount : 0; }
+int rt_bvh_fallback_splits(const rt_bvh *b) { return b ? b->bvh.fallback_splits : 0; }
+void rt_bvh_destroy(rt_bvh *b) { delete b; }
+
+// ---------------------------------------------------------------- rays
+int rt_primary_rays(int W, int H, const float origin[3], rt_ray_isect *out)
+{
+  if (W <= 0 || H <= 0 || !origin || !out) return Fail(RT_ERR_INVALID, "bad primary-ray arguments");
+  rt::PrimaryRays(W, H, origin, out);
+  return RT_OK;
+}
+
+int rt_frame_camera(const rt_aabb *root, int W, int H, float origin_out[3])
+{
+  if (!root || !origin_out || W <= 0 || H <= 0) return Fail(RT_ERR_INVALID, "bad camera arguments");
+  rt::FrameCamera(*root, W, H, origin_out);
+  return RT_OK;
+}
+
+int rt_ao_rays(const rt_mesh *m, const rt_aabb *root, uint64_t seed, size_t first, size_t count, rt_ray_isect *out)
+{
+  if (!m || !root || !out) return Fail(RT_ERR_INVALID, "null argument");
+  if (m->mesh.faces.empty()) return Fail(RT_ERR_INVALID, "mesh has no triangles");
+  for (auto const &f : m->mesh.faces)
+    if (f.s[0] >= m->mesh.verts.size() || f.s[1] >= m->mesh.verts.size() || f.s[2] >= m->mesh.verts.size())
+      return Fail(RT_ERR_INVALID, "face vertex index out of range");
+  rt::AoRays(m->mesh.verts.data(), m->mesh.faces.data(), m->mesh.faces.size(), *root, seed, first, count, out);
+  return RT_OK;
+}
+
+// ---------------------------------------------------------------- scene
+int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, size_t ntris,
+                    const rt_float4 *normals, size_t nnormals, const rt_material *materials, size_t nmats,
+                    const rt_bvh_node *bvh_nodes, size_t nnodes, int device, unsigned flags, rt_scene **out)
+{
+  if (!out || !verts || !faces || !bvh_nodes) return Fail(RT_ERR_INVALID, "null argument");
+  if ((!normals && nnormals) || (!materials && nmats)) return Fail(RT_ERR_INVALID, "null argument");
+  if (flags != RT_SCENE_WIDE2 && flags != RT_SCENE_WIDE4) return Fail(RT_ERR_INVALID, "unknown scene flags");
+  int ndev = 0;
+  RT_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return Fail(RT_ERR_DEVICE, "no such HIP device");
+
+  rt_scene *s = new (std::nothrow) rt_scene;
+  if (!s) return Fail(RT_ERR_NOMEM, "out of memory");
+  std::string why;
+  try {
+    why = rt::Flatten(bvh_nodes, nnodes, verts, nverts, faces, ntris, &s->flat);
+  } catch (const std::exception &ex) {
+    why = ex.what();
+  }
+  if (!why.empty()) {
+    delete s;
+    return Fail(RT_ERR_INVALID, "bad scene: " + why);
+  }
+  s->device = device;
+  s->width = flags == RT_SCENE_WIDE4 ? 4 : 2;
+  s->nverts = nverts; s->ntris = ntris; s->nnormals = nnormals; s->nmats = nmats;
+  if (const char *e = std::getenv("RT_PERSISTENT")) s->persistent = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RT_BLOCKS_PER_CU")) s->blocks_per_cu = std::max(1, std::atoi(e));
+
+  DeviceGuard guard(device);
+  int rc = guard.ok ? RT_OK : Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  hipDeviceProp_t prop;
+  if (rc == RT_OK && hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cu = prop.multiProcessorCount;
+  if (rc == RT_OK) rc = Upload(&s->d_nodes2, s->flat.nodes2.data(), s->flat.nodes2.size() * sizeof(rt::GpuNode2));
+  if (rc == RT_OK) rc = Upload(&s->d_nodes4, s->flat.nodes4.data(), s->flat.nodes4.size() * sizeof(rt::GpuNode4));
+  if (rc == RT_OK) rc = Upload(&s->d_tris, s->flat.tris.data(), s->flat.tris.size() * sizeof(rt::GpuTri));
+  if (rc == RT_OK) rc = Upload(&s->d_verts, verts, nverts * sizeof(rt_vec3));
+  if (rc == RT_OK) rc = Upload(&s->d_faces, faces, ntris * sizeof(rt_face));
+  if (rc == RT_OK) rc = Upload(&s->d_normals, normals, nnormals * sizeof(rt_float4));
+  if (rc == RT_OK) rc = Upload(&s->d_mats, materials, nmats * sizeof(rt_material));
+  if (rc == RT_OK) rc = Upload(&s->d_counters, nullptr, kCounterSlots * kCounterStride * sizeof(uint32_t));
+  if (rc == RT_OK) rc = Upload(&s->d_stats, nullptr, 8 * sizeof(unsigned long long));
+  if (rc != RT_OK) {
+    std::string keep = g_error;
+    rt_scene_destroy(s);
+    g_error = keep;
+    return rc;
+  }
+  *out = s;
+  return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene *s)
+{
+  if (!s) return;
+  DeviceGuard guard(s->device);
+  (void)hipFree(s->d_nodes2); (void)hipFree(s->d_nodes4); (void)hipFree(s->d_tris);
+  (void)hipFree(s->d_verts); (void)hipFree(s->d_faces); (void)hipFree(s->d_normals); (void)hipFree(s->d_mats);
+  (void)hipFree(s->d_counters); (void)hipFree(s->d_stats);
+  (void)hipFree(s->d_stage_in); (void)hipFree(s->d_stage_out);
+  delete s;
+}
+
+int rt_scene_info(const rt_scene *s, uint64_t info[8])
+{
+  if (!s || !info) return Fail(RT_ERR_INVALID, "null argument");
+  info[0] = s->flat.nodes2.size(); info[1] = s->flat.nodes4.size(); info[2] = s->flat.tris.size();
+  info[3] = static_cast<uint64_t>(s->flat.depth2); info[4] = static_cast<uint64_t>(s->flat.depth4);
+  info[5] = sizeof(rt::GpuNode2); info[6] = sizeof(rt::GpuNode4); info[7] = sizeof(rt::GpuTri);
+  return RT_OK;
+}
+
+int rt_scene_set_param(rt_scene *s, const char *key, int value)
+{
+  if (!s || !key) return Fail(RT_ERR_INVALID, "null argument");
+  const std::string k(key);
+  if (k == "width") {
+    if (value != 2 && value != 4) return Fail(RT_ERR_INVALID, "width must be 2 or 4");
+    s->width = value;
+  } else if (k == "persistent") {
+    s->persistent = value != 0;
+  } else if (k == "blocks_per_cu") {
+    if (value < 1 || value > 64) return Fail(RT_ERR_INVALID, "blocks_per_cu out of range");
+    s->blocks_per_cu = value;
+  } else {
+    return Fail(RT_ERR_INVALID, "unknown parameter " + k);
+  }
+  return RT_OK;
+}
+
+// ---------------------------------------------------------------- hot path
+int rt_intersect_async(const rt_scene *s, const void *rays_dev, size_t n, void *hits_dev, void *hits16_dev,
+                       void *stream)
+{
+  if (!s) return Fail(RT_ERR_INVALID, "null scene");
+  if (n == 0) return RT_OK;
+  if (!rays_dev || (!hits_dev && !hits16_dev)) return Fail(RT_ERR_INVALID, "null ray or hit buffer");
+  DeviceGuard guard(s->device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  for (size_t off = 0; off < n; off += kChunk) {
+    rt::KernelArgs a;
+    FillArgs(s, a);
+    a.rays = static_cast<const rt_ray_isect *>(rays_dev) + off;
+    a.hits = hits_dev ? static_cast<rt_ray_isect *>(hits_dev) + off : nullptr;
+    a.hits16 = hits16_dev ? static_cast<rt_hit16 *>(hits16_dev) + off : nullptr;
+    a.n = static_cast<uint32_t>(std::min(kChunk, n - off));
+    int rc = Enqueue(s, a, rt::kModeIntersect, false, static_cast<hipStream_t>(stream));
+    if (rc != RT_OK) return rc;
+  }
+  return RT_OK;
+}
+
+int ray_scene_intersection(const void *rays, size_t n, const rt_scene *scene, void *hits)
+{
+  if (!scene) return Fail(RT_ERR_INVALID, "null scene");
+  if (n == 0) return RT_OK;
+  if (!rays || !hits) return Fail(RT_ERR_INVALID, "null ray or hit buffer");
+  if (n > (SIZE_MAX / sizeof(rt_ray_isect))) return Fail(RT_ERR_INVALID, "ray count overflows");
+  DeviceGuard guard(scene->device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  const size_t bytes = n * sizeof(rt_ray_isect);
+  const bool in_dev = IsDevicePointer(rays), out_dev = IsDevicePointer(hits);
+  const void *d_in = rays;
+  void *d_out = hits;
+  if (!in_dev) {
+    int rc = EnsureStage(&scene->d_stage_in, &scene->stage_in_bytes, bytes);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipMemcpy(scene->d_stage_in, rays, bytes, hipMemcpyHostToDevice));
+    d_in = scene->d_stage_in;
+  }
+  if (!out_dev) {
+    int rc = EnsureStage(&scene->d_stage_out, &scene->stage_out_bytes, bytes);
+    if (rc != RT_OK) return rc;
+    d_out = scene->d_stage_out;
+  }
+  int rc = rt_intersect_async(scene, d_in, n, d_out, nullptr, nullptr);
+  if (rc != RT_OK) return rc;
+  RT_HIP(hipStreamSynchronize(nullptr));
+  if (!out_dev) RT_HIP(hipMemcpy(hits, d_out, bytes, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_trace_pass(const rt_scene *s, const void *rays_in_dev, void *rays_out_dev, float *rgba_dev, size_t n,
+                  const float cam[16], unsigned trace_operation, void *stream)
+{
+  if (!s) return Fail(RT_ERR_INVALID, "null scene");
+  if (trace_operation > 1) return Fail(RT_ERR_INVALID, "trace_operation must be 0 or 1");
+  if (n == 0) return RT_OK;
+  if (!rays_in_dev || (!rays_out_dev && !rgba_dev)) return Fail(RT_ERR_INVALID, "null ray or output buffer");
+  if (trace_operation == 0 && !cam) return Fail(RT_ERR_INVALID, "camera matrix required for operation 0");
+  if (rays_in_dev == rays_out_dev) return Fail(RT_ERR_INVALID, "input and output records must not alias");
+  DeviceGuard guard(s->device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  for (size_t off = 0; off < n; off += kChunk) {
+    rt::KernelArgs a;
+    FillArgs(s, a);
+    a.rays = static_cast<const rt_ray_isect *>(rays_in_dev) + off;
+    a.hits = rays_out_dev ? static_cast<rt_ray_isect *>(rays_out_dev) + off : nullptr;
+    a.rgba = rgba_dev ? rgba_dev + off * 4 : nullptr;
+    a.n = static_cast<uint32_t>(std::min(kChunk, n - off));
+    a.op = trace_operation;
+    if (cam) std::memcpy(a.cam, cam, sizeof a.cam);
+    int rc = Enqueue(s, a, rt::kModeTrace, false, static_cast<hipStream_t>(stream));
+    if (rc != RT_OK) return rc;
+  }
+  return RT_OK;
+}
+
+int rt_scene_count_fetches(const rt_scene *s, const rt_ray_isect *rays_host, size_t n, size_t stride,
+                           uint64_t counts[5])
+{
+  if (!s || !rays_host || !counts) return Fail(RT_ERR_INVALID, "null argument");
+  if (stride == 0) stride = 1;
+  rt::FetchCounts fc = rt::CountFetches(s->flat, s->width, rays_host, n, stride);
+  counts[0] = fc.nodes; counts[1] = fc.tris; counts[2] = fc.leaves; counts[3] = fc.rays_hit;
+  counts[4] = (n + stride - 1) / stride;
+  return RT_OK;
+}
+
+int rt_scene_count_fetches_device(const rt_scene *s, const void *rays_dev, size_t n, uint64_t counts[5])
+{
+  if (!s || !rays_dev || !counts) return Fail(RT_ERR_INVALID, "null argument");
+  if (n == 0 || n > kChunk) return Fail(RT_ERR_INVALID, "ray count out of range for the instrumented kernel");
+  DeviceGuard guard(s->device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  RT_HIP(hipMemset(s->d_stats, 0, 8 * sizeof(unsigned long long)));
+  int rc = EnsureStage(&s->d_stage_out, &s->stage_out_bytes, n * sizeof(rt_hit16));
+  if (rc != RT_OK) return rc;
+  rt::KernelArgs a;
+  FillArgs(s, a);
+  a.rays = static_cast<const rt_ray_isect *>(rays_dev);
+  a.hits16 = static_cast<rt_hit16 *>(s->d_stage_out);
+  a.n = static_cast<uint32_t>(n);
+  rc = Enqueue(s, a, rt::kModeIntersect, true, nullptr);
+  if (rc != RT_OK) return rc;
+  unsigned long long h[4];
+  RT_HIP(hipMemcpy(h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 4; ++i) counts[i] = h[i];
+  counts[4] = n;
+  return RT_OK;
+}
+
+int rt_debug_tri_batch(int device, const rt_vec3 *tri, const rt_ray *ray, size_t n, int32_t *hit, float *t, rt_vec2 *uv)
+{
+  if (!tri || !ray || !hit || !t || !uv) return Fail(RT_ERR_INVALID, "null argument");
+  if (n == 0) return RT_OK;
+  if (n > (size_t(1) << 28)) return Fail(RT_ERR_INVALID, "batch too large");
+  DeviceGuard guard(device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  rt_vec3 *d_tri = nullptr; rt_ray *d_ray = nullptr; int32_t *d_hit = nullptr; float *d_t = nullptr; rt_vec2 *d_uv = nullptr;
+  int rc = Upload(&d_tri, tri, n * 3 * sizeof(rt_vec3));
+  if (rc == RT_OK) rc = Upload(&d_ray, ray, n * sizeof(rt_ray));
+  if (rc == RT_OK) rc = Upload(&d_hit, nullptr, n * sizeof(int32_t));
+  if (rc == RT_OK) rc = Upload(&d_t, nullptr, n * sizeof(float));
+  if (rc == RT_OK) rc = Upload(&d_uv, nullptr, n * sizeof(rt_vec2));
+  if (rc == RT_OK) {
+    hipError_t e = rt::LaunchTriBatch(d_tri, d_ray, static_cast<uint32_t>(n), d_hit, d_t, d_uv, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(hit, d_hit, n * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(uv, d_uv, n * sizeof(rt_vec2), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = FailHip(e, "tri batch");
+  }
+  (void)hipFree(d_tri); (void)hipFree(d_ray); (void)hipFree(d_hit); (void)hipFree(d_t); (void)hipFree(d_uv);
+  return rc;
+}
+
+// ---------------------------------------------------------------- framebuffer out
+int rt_write_bmp32(const char *path, const uint8_t *bgra, int width, int height)
+{
+  if (!path || !bgra || width <= 0 || height <= 0) return Fail(RT_ERR_INVALID, "bad image arguments");
+  if (!rt::WriteBmp32(path, bgra, width, height)) return Fail(RT_ERR_IO, std::string("cannot write ") + path);
+  return RT_OK;
+}
+
+int rt_write_pfm(const char *path, const float *rgba, int width, int height)
+{
+  if (!path || !rgba || width <= 0 || height <= 0) return Fail(RT_ERR_INVALID, "bad image arguments");
+  if (!rt::WritePfm(path, rgba, width, height)) return Fail(RT_ERR_IO, std::string("cannot write ") + path);
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+// flatten.cpp -- turns the reference's 80-byte parent-linked AoS node array
+// (core/CentroidBVH.h:52-59) into the two device layouts and counts, on the host, how
+// many records a ray fetches from them.
+//
+// The reference layout stores each node's OWN box, so visiting a child costs a second
+// dependent line; its traversal walks parent links (render_client/tracekernel.ck:115-138).
+// Here a node record carries its CHILDREN's boxes and references: one fetch decides both
+// (BVH2, 64 B) or all four (BVH4, 128 B = one cache line) descents, leaves are folded into
+// the parent's reference, and triangles are pre-gathered in leaf order so a leaf is one
+// contiguous run of 48-byte records (the reference needs a 32-byte index record plus three
+// dependent 16-byte vertex fetches per triangle, tracekernel.ck:159-162).
+#include "host_scene.h"
+#include "trace_math.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace rt {
+
+namespace {
+
+inline float Area(rt_aabb const &b)
+{
+  float x = b.b.x - b.a.x, y = b.b.y - b.a.y, z = b.b.z - b.a.z;
+  return x * y + y * z + z * x;
+}
+
+}  // namespace
+
+std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *verts, size_t nverts,
+                    rt_face const *faces, size_t ntris, FlatScene *out)
+{
+  *out = FlatScene();
+  if (!nodes || nnodes < 3) return "bvh needs a root with two children";
+  if (nodes[0].type != RT_BVH_INNER) return "bvh root must be an inner node";
+  if (ntris >= (1u << 28)) return "too many triangles for the 28-bit leaf reference";
+
+  // ---- validate + number inner nodes and triangles in depth-first pre-order -------
+  std::vector<uint32_t> inner_id(nnodes, 0xFFFFFFFFu), leaf_ref(nnodes, 0);
+  std::vector<uint8_t> seen(nnodes, 0);
+  std::vector<uint32_t> order;  // reference indices of inner nodes, in new order
+  struct Item { uint32_t node; int depth; };
+  std::vector<Item> todo{{0u, 1}};
+  seen[0] = 1;
+  int max_depth = 0;
+  while (!todo.empty()) {
+    Item it = todo.back();
+    todo.pop_back();
+    rt_bvh_node const &n = nodes[it.node];
+    if (n.type == RT_BVH_INNER) {
+      inner_id[it.node] = static_cast<uint32_t>(order.size());
+      order.push_back(it.node);
+      max_depth = std::max(max_depth, it.depth);
+      for (int k = 1; k >= 0; --k) {  // child 0 is processed first
+        uint32_t c = n.node.inner.children_index[k];
+        if (c >= nnodes) return "child index out of range";
+        if (seen[c]) return "bvh is not a tree (node reached twice)";
+        seen[c] = 1;
+        todo.push_back({c, it.depth + 1});
+      }
+    } else if (n.type == RT_BVH_LEAF) {
+      uint32_t cnt = n.node.leaf.count;
+      if (cnt > RT_TRIS_PER_LEAF) return "leaf holds more than 4 triangles";
+      uint32_t first = static_cast<uint32_t>(out->tris.size());
+      for (uint32_t j = 0; j < cnt; ++j) {
+        uint32_t t = n.node.leaf.tris[j];
+        if (t >= ntris) return "leaf triangle index out of range";
+        rt_face const &f = faces[t];
+        if (f.s[0] >= nverts || f.s[1] >= nverts || f.s[2] >= nverts) return "face vertex index out of range";
+        rt_vec3 const &a = verts[f.s[0]], &b = verts[f.s[1]], &c = verts[f.s[2]];
+        GpuTri g;
+        g.ax = a.x; g.ay = a.y; g.az = a.z; g.id = t;
+        g.e1x = b.x - a.x; g.e1y = b.y - a.y; g.e1z = b.z - a.z; g.pad0 = 0;
+        g.e2x = c.x - a.x; g.e2y = c.y - a.y; g.e2z = c.z - a.z; g.pad1 = 0;
+        out->tris.push_back(g);
+      }
+      leaf_ref[it.node] = kLeafBit | (first << 3) | cnt;
+    } else {
+      return "unknown node type";
+    }
+  }
+
+  auto ref_of = [&](uint32_t node) { return nodes[node].type == RT_BVH_INNER ? inner_id[node] : leaf_ref[node]; };
+
+  // ---- BVH2 records ---------------------------------------------------------------
+  out->nodes2.resize(order.size());
+  for (size_t i = 0; i < order.size(); ++i) {
+    rt_bvh_node const &n = nodes[order[i]];
+    GpuNode2 g;
+    std::memset(&g, 0, sizeof g);
+    const uint32_t c0 = n.node.inner.children_index[0], c1 = n.node.inner.children_index[1];
+    rt_aabb const &b0 = nodes[c0].aabb, &b1 = nodes[c1].aabb;
+    g.lo0[0] = b0.a.x; g.lo0[1] = b0.a.y; g.lo0[2] = b0.a.z; g.hi0[0] = b0.b.x; g.hi0[1] = b0.b.y; g.hi0[2] = b0.b.z;
+    g.lo1[0] = b1.a.x; g.lo1[1] = b1.a.y; g.lo1[2] = b1.a.z; g.hi1[0] = b1.b.x; g.hi1[1] = b1.b.y; g.hi1[2] = b1.b.z;
+    g.child[0] = ref_of(c0);
+    g.child[1] = ref_of(c1);
+    out->nodes2[i] = g;
+  }
+  out->depth2 = max_depth;
+  out->stack2 = max_depth + 1;
+
+  // ---- BVH4: pull grandchildren up, largest box first -----------------------------
+  // Each BVH4 node is rooted at a BVH2 inner node; the set {child0, child1} is widened by
+  // replacing its largest inner member with that member's two children until it holds four
+  // entries or only leaves.
+  {
+    std::vector<uint32_t> id4(nnodes, 0xFFFFFFFFu);
+    struct Pending { uint32_t root; int depth; };
+    std::vector<Pending> q{{0u, 1}};
+    std::vector<std::array<uint32_t, 4>> kids;
+    std::vector<int> nk;
+    id4[0] = 0;
+    std::vector<uint32_t> roots{0u};
+    std::vector<int> depths{1};
+    int max4 = 0;
+    for (size_t qi = 0; qi < roots.size(); ++qi) {  // breadth-first numbering keeps the top levels dense
+      const uint32_t r = roots[qi];
+      max4 = std::max(max4, depths[qi]);
+      uint32_t set[4] = {nodes[r].node.inner.children_index[0], nodes[r].node.inner.children_index[1], 0, 0};
+      int n = 2;
+      while (n < 4) {
+        int pick = -1;
+        float best = -1.f;
+        for (int k = 0; k < n; ++k)
+          if (nodes[set[k]].type == RT_BVH_INNER) {
+            float a = Area(nodes[set[k]].aabb);
+            if (a > best) { best = a; pick = k; }
+          }
+        if (pick < 0) break;
+        const uint32_t p = set[pick];
+        set[pick] = nodes[p].node.inner.children_index[0];
+        set[n++] = nodes[p].node.inner.children_index[1];
+      }
+      std::array<uint32_t, 4> ks{};
+      for (int k = 0; k < n; ++k) {
+        ks[k] = set[k];
+        if (nodes[set[k]].type == RT_BVH_INNER) {
+          id4[set[k]] = static_cast<uint32_t>(roots.size());
+          roots.push_back(set[k]);
+          depths.push_back(depths[qi] + 1);
+        }
+      }
+      kids.push_back(ks);
+      nk.push_back(n);
+    }
+    out->nodes4.resize(roots.size());
+    for (size_t i = 0; i < roots.size(); ++i) {
+      GpuNode4 g;
+      std::memset(&g, 0, sizeof g);
+      for (int k = 0; k < 4; ++k) {
+        if (k < nk[i]) {
+          rt_aabb const &b = nodes[kids[i][k]].aabb;
+          g.lox[k] = b.a.x; g.loy[k] = b.a.y; g.loz[k] = b.a.z;
+          g.hix[k] = b.b.x; g.hiy[k] = b.b.y; g.hiz[k] = b.b.z;
+          g.child[k] = nodes[kids[i][k]].type == RT_BVH_INNER ? id4[kids[i][k]] : leaf_ref[kids[i][k]];
+        } else {  // unused slot: inverted box never passes the slab test
+          g.lox[k] = g.loy[k] = g.loz[k] = kFltMax;
+          g.hix[k] = g.hiy[k] = g.hiz[k] = -kFltMax;
+          g.child[k] = kEmptyRef;
+        }
+      }
+      out->nodes4[i] = g;
+    }
+    out->depth4 = max4;
+    out->stack4 = 3 * max4 + 1;
+    (void)q;
+  }
+
+  out->root_box = nodes[0].aabb;
+  float s = 0.f;
+  for (float v : {nodes[0].aabb.a.x, nodes[0].aabb.a.y, nodes[0].aabb.a.z, nodes[0].aabb.b.x, nodes[0].aabb.b.y,
+                  nodes[0].aabb.b.z})
+    s = std::max(s, std::fabs(v));
+  out->scale = s;
+  return std::string();
+}
+
+// Host mirror of the device traversal (same order, same arithmetic) that only counts.
+FetchCounts CountFetches(FlatScene const &fs, int width, rt_ray_isect const *rays, size_t nrays, size_t stride)
+{
+  FetchCounts fc;
+  if (stride == 0) stride = 1;
+  std::vector<uint32_t> stack(static_cast<size_t>(std::max(fs.stack2, fs.stack4)) + 8);
+  for (size_t k = 0; k < nrays; k += stride) {
+    RayCtx r;
+    SetupRay(r, rays[k].origin.x, rays[k].origin.y, rays[k].origin.z, rays[k].direction.x, rays[k].direction.y,
+             rays[k].direction.z, fs.scale);
+    float tbest = kFltMax;
+    uint32_t best = 0xFFFFFFFFu;
+    size_t sp = 0;
+    uint32_t cur = 0;
+    for (;;) {
+      if (!(cur & kLeafBit)) {
+        fc.nodes++;
+        uint32_t hit_ref[4];
+        float hit_t[4];
+        int nh = 0;
+        if (width == 4) {
+          GpuNode4 const &n = fs.nodes4[cur];
+          for (int c = 0; c < 4; ++c) {
+            float te;
+            if (SlabTest(r, n.lox[c], n.loy[c], n.loz[c], n.hix[c], n.hiy[c], n.hiz[c], tbest, te)) {
+              hit_ref[nh] = n.child[c];
+              hit_t[nh++] = te;
+            }
+          }
+        } else {
+          GpuNode2 const &n = fs.nodes2[cur];
+          float te;
+          if (SlabTest(r, n.lo0[0], n.lo0[1], n.lo0[2], n.hi0[0], n.hi0[1], n.hi0[2], tbest, te)) {
+            hit_ref[nh] = n.child[0];
+            hit_t[nh++] = te;
+          }
+          if (SlabTest(r, n.lo1[0], n.lo1[1], n.lo1[2], n.hi1[0], n.hi1[1], n.hi1[2], tbest, te)) {
+            hit_ref[nh] = n.child[1];
+            hit_t[nh++] = te;
+          }
+        }
+        // nearest first; stable for equal entry distances (lower slot first)
+        for (int i = 1; i < nh; ++i)
+          for (int j = i; j > 0 && hit_t[j] < hit_t[j - 1]; --j) {
+            std::swap(hit_t[j], hit_t[j - 1]);
+            std::swap(hit_ref[j], hit_ref[j - 1]);
+          }
+        for (int i = nh - 1; i >= 1; --i) stack[sp++] = hit_ref[i];
+        fc.max_stack = std::max<uint64_t>(fc.max_stack, sp);
+        if (nh > 0) { cur = hit_ref[0]; continue; }
+      } else {
+        const uint32_t first = (cur & ~kLeafBit) >> 3, cnt = cur & 7u;
+        if (cnt) fc.leaves++;
+        for (uint32_t j = 0; j < cnt; ++j) {
+          GpuTri const &g = fs.tris[first + j];
+          fc.tris++;
+          float t, u, v;
+          if (TriTest(g.ax, g.ay, g.az, g.e1x, g.e1y, g.e1z, g.e2x, g.e2y, g.e2z, r, t, u, v) &&
+              (t < tbest || (t == tbest && g.id < best))) {
+            tbest = t;
+            best = g.id;
+          }
+        }
+      }
+      if (sp == 0) break;
+      cur = stack[--sp];
+    }
+    if (best != 0xFFFFFFFFu) fc.rays_hit++;
+  }
+  return fc;
+}
+
+}  // namespace rt

@@ -1,0 +1,307 @@
+// trace_kernels.hip -- gfx950 closest-hit kernels (wave64, FP32 VALU, no MFMA: there is
+// no dense contraction on this path).
+//
+// What the kernel computes per ray is what one work-item of the reference's `trace`
+// kernel computes (render_client/tracekernel.ck:192-414): optional ray setup (:224-265),
+// closest hit over the BVH (:271-370), output record and pixel (:373-413).  How it gets
+// there is different:
+//   * nodes hold their children's boxes (64 B two-wide or 128 B four-wide records), so
+//     one coalescable record fetch replaces the reference's two or three dependent
+//     80-byte node reads per step (near_child_impl/parent_impl/sibling_impl, :115-138);
+//   * an explicit per-lane stack in LDS, laid out [entry][lane] so a wave's pushes and
+//     pops never bank-conflict, replaces the parent-link state machine (:291-370);
+//   * leaves are runs of 48-byte pre-gathered triangle records instead of index ->
+//     3 x vertex gathers (:159-162);
+//   * waves are persistent and pull 64 rays at a time from a global counter with one
+//     atomic per wave, so a slow tile does not idle the rest of its workgroup's slot;
+//   * reciprocal directions are computed once per ray, not once per box (:73);
+//   * the closest hit is order-independent: on equal t the lower triangle index wins,
+//     which is what an index-order brute-force loop with a strict `<` returns
+//     (cpu_raycast/raycast.cpp:113-122).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/rt_layout.h"
+#include "device_scene.h"
+#include "trace_math.h"
+
+namespace rt {
+
+namespace {
+
+constexpr uint32_t kDone = 0xFFFFFFFFu;
+
+__device__ __forceinline__ float4 LoadF4(const float4 *p) { return *p; }
+
+struct Best {
+  float t, u, v;
+  uint32_t id;
+};
+
+template <bool COUNT>
+__device__ __forceinline__ void LeafTest(const KernelArgs &p, const RayCtx &r, uint32_t ref, Best &b, uint32_t &ntri)
+{
+  const uint32_t first = (ref & 0x7FFFFFFFu) >> 3, cnt = ref & 7u;
+  const float4 *tp = p.tris + static_cast<size_t>(first) * 3u;
+  for (uint32_t j = 0; j < cnt; ++j) {
+    const float4 a = LoadF4(tp + 3 * j), e1 = LoadF4(tp + 3 * j + 1), e2 = LoadF4(tp + 3 * j + 2);
+    float t, u, v;
+    const bool ok = TriTest(a.x, a.y, a.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z, r, t, u, v);
+    const uint32_t id = __float_as_uint(a.w);
+    if (ok && (t < b.t || (t == b.t && id < b.id))) {
+      b.t = t; b.u = u; b.v = v; b.id = id;
+    }
+    if (COUNT) ntri++;
+  }
+}
+
+// One step at a two-wide node: returns the next reference to visit (kDone if the stack ran dry).
+__device__ __forceinline__ uint32_t Step2(const KernelArgs &p, const RayCtx &r, uint32_t cur, float tbest,
+                                          uint32_t *stk, uint32_t &sp)
+{
+  const float4 *np = p.nodes + static_cast<size_t>(cur) * 4u;
+  const float4 q0 = LoadF4(np), q1 = LoadF4(np + 1), q2 = LoadF4(np + 2);
+  const uint4 q3 = *reinterpret_cast<const uint4 *>(np + 3);
+  float t0, t1;
+  const bool h0 = SlabTest(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tbest, t0);
+  const bool h1 = SlabTest(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tbest, t1);
+  if (h0 && h1) {
+    const bool swap = t1 < t0;
+    stk[sp * 64u] = swap ? q3.x : q3.y;
+    sp++;
+    return swap ? q3.y : q3.x;
+  }
+  if (h0) return q3.x;
+  if (h1) return q3.y;
+  if (sp == 0) return kDone;
+  return stk[--sp * 64u];
+}
+
+// One step at a four-wide node.
+__device__ __forceinline__ uint32_t Step4(const KernelArgs &p, const RayCtx &r, uint32_t cur, float tbest,
+                                          uint32_t *stk, uint32_t &sp)
+{
+  const float4 *np = p.nodes + static_cast<size_t>(cur) * 8u;
+  const float4 lox = LoadF4(np), loy = LoadF4(np + 1), loz = LoadF4(np + 2);
+  const float4 hix = LoadF4(np + 3), hiy = LoadF4(np + 4), hiz = LoadF4(np + 5);
+  const uint4 ch = *reinterpret_cast<const uint4 *>(np + 6);
+  float t0, t1, t2, t3;
+  const bool h0 = SlabTest(r, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, tbest, t0);
+  const bool h1 = SlabTest(r, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, tbest, t1);
+  const bool h2 = SlabTest(r, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, tbest, t2);
+  const bool h3 = SlabTest(r, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, tbest, t3);
+  const uint32_t nh = uint32_t(h0) + uint32_t(h1) + uint32_t(h2) + uint32_t(h3);
+  if (nh == 0) {
+    if (sp == 0) return kDone;
+    return stk[--sp * 64u];
+  }
+  // rank = number of hit children strictly nearer, or equally near with a lower slot
+  const uint32_t r0 = uint32_t(h1 && t1 < t0) + uint32_t(h2 && t2 < t0) + uint32_t(h3 && t3 < t0);
+  const uint32_t r1 = uint32_t(h0 && t0 <= t1) + uint32_t(h2 && t2 < t1) + uint32_t(h3 && t3 < t1);
+  const uint32_t r2 = uint32_t(h0 && t0 <= t2) + uint32_t(h1 && t1 <= t2) + uint32_t(h3 && t3 < t2);
+  const uint32_t r3 = uint32_t(h0 && t0 <= t3) + uint32_t(h1 && t1 <= t3) + uint32_t(h2 && t2 <= t3);
+  // farthest goes deepest: rank k >= 1 lands at sp + (nh - 1 - k)
+  const uint32_t top = sp + nh - 1u;
+  if (h0 && r0) stk[(top - r0) * 64u] = ch.x;
+  if (h1 && r1) stk[(top - r1) * 64u] = ch.y;
+  if (h2 && r2) stk[(top - r2) * 64u] = ch.z;
+  if (h3 && r3) stk[(top - r3) * 64u] = ch.w;
+  sp = top;
+  uint32_t next = ch.w;
+  if (h2 && r2 == 0) next = ch.z;
+  if (h1 && r1 == 0) next = ch.y;
+  if (h0 && r0 == 0) next = ch.x;
+  return next;
+}
+
+__device__ __forceinline__ float Dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+template <int WIDTH, int MODE, bool PERSISTENT, bool COUNT>
+__global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
+{
+  extern __shared__ uint32_t lds_stack[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t *stk = lds_stack + wave * p.stack_entries * 64u + lane;
+
+  for (uint32_t round = 0;; ++round) {
+    uint32_t base;
+    if (PERSISTENT) {
+      uint32_t got = 0;
+      if (lane == 0) got = atomicAdd(p.counter, 64u);
+      base = __builtin_amdgcn_readfirstlane(got);
+    } else {
+      base = (blockIdx.x * 4u + wave) * 64u;
+      if (round) break;
+    }
+    if (base >= p.n) break;
+    const uint32_t idx = base + lane;
+    if (idx < p.n) {
+      const float4 *rp = reinterpret_cast<const float4 *>(p.rays + idx);
+      const float4 in_o = LoadF4(rp), in_d = LoadF4(rp + 1);
+      float ox = in_o.x, oy = in_o.y, oz = in_o.z, dx = in_d.x, dy = in_d.y, dz = in_d.z;
+      bool live = true;
+      if (MODE == kModeTrace) {
+        if (p.op == 1u) {
+          // reflect about the stored normal and step off the surface (tracekernel.ck:101-104,227-233)
+          const float4 nn = LoadF4(rp + 2);
+          const float s = 2.0f * Dot4(in_d, nn);
+          dx = in_d.x - s * nn.x; dy = in_d.y - s * nn.y; dz = in_d.z - s * nn.z;
+          ox = in_o.x + nn.x * 0.00001f; oy = in_o.y + nn.y * 0.00001f; oz = in_o.z + nn.z * 0.00001f;
+          // a ray that missed in the previous pass stays terminated
+          live = p.rays[idx].triangle_id != RT_MISS_ID;
+        } else {
+          // camera matrix rows dotted with (origin,1) and (direction,0) (tracekernel.ck:182-190,251-265)
+          const float4 o4 = make_float4(ox, oy, oz, 1.f), d4 = make_float4(dx, dy, dz, 0.f);
+          const float4 m0 = make_float4(p.cam[0], p.cam[1], p.cam[2], p.cam[3]);
+          const float4 m1 = make_float4(p.cam[4], p.cam[5], p.cam[6], p.cam[7]);
+          const float4 m2 = make_float4(p.cam[8], p.cam[9], p.cam[10], p.cam[11]);
+          ox = Dot4(m0, o4); oy = Dot4(m1, o4); oz = Dot4(m2, o4);
+          dx = Dot4(m0, d4); dy = Dot4(m1, d4); dz = Dot4(m2, d4);
+        }
+      }
+
+      RayCtx r;
+      SetupRay(r, ox, oy, oz, dx, dy, dz, p.scale);
+      Best best{kFltMax, 0.f, 0.f, RT_MISS_ID};
+      uint32_t sp = 0, cur = live ? 0u : kDone;
+      uint32_t nnode = 0, ntri = 0, nleaf = 0;
+
+      while (cur != kDone) {
+        // descend through inner records until this lane holds a leaf (or runs dry)
+        while (!(cur & kLeafBitDev)) {
+          if (COUNT) nnode++;
+          cur = (WIDTH == 4) ? Step4(p, r, cur, best.t, stk, sp) : Step2(p, r, cur, best.t, stk, sp);
+        }
+        if (cur != kDone) {
+          if (COUNT) nleaf += (cur & 7u) ? 1u : 0u;
+          LeafTest<COUNT>(p, r, cur, best, ntri);
+          cur = sp ? stk[--sp * 64u] : kDone;
+        }
+      }
+
+      if (COUNT) {
+        atomicAdd(p.stats + 0, static_cast<unsigned long long>(nnode));
+        atomicAdd(p.stats + 1, static_cast<unsigned long long>(ntri));
+        atomicAdd(p.stats + 2, static_cast<unsigned long long>(nleaf));
+        atomicAdd(p.stats + 3, static_cast<unsigned long long>(best.id != RT_MISS_ID ? 1u : 0u));
+      }
+
+      // ---- output record (tracekernel.ck:282-286 miss defaults, :373-399 hit) ----------
+      const bool hit = best.id != RT_MISS_ID;
+      if (p.hits16) {
+        rt_hit16 h;
+        h.triangle_id = best.id; h.t = best.t; h.u = hit ? best.u : 0.f; h.v = hit ? best.v : 0.f;
+        *reinterpret_cast<float4 *>(p.hits16 + idx) =
+            make_float4(__uint_as_float(h.triangle_id), h.t, h.u, h.v);
+      }
+      float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.hits || (MODE == kModeTrace && p.rgba)) {
+        float4 out_o = in_o, out_n = in_d, out_d = in_d;
+        float out_u = 0.f, out_v = 0.f;
+        if (MODE == kModeTrace && !live) {
+          out_n = LoadF4(rp + 2);  // terminated record passes through unchanged
+        }
+        if (hit) {
+          const rt_face f = p.faces[best.id];
+          const float u = best.u, v = best.v, w = 1.f - u - v;
+          const float4 v0 = *reinterpret_cast<const float4 *>(p.verts + f.s[0]);
+          const float4 v1 = *reinterpret_cast<const float4 *>(p.verts + f.s[1]);
+          const float4 v2 = *reinterpret_cast<const float4 *>(p.verts + f.s[2]);
+          out_o = make_float4(w * v0.x + u * v1.x + v * v2.x, w * v0.y + u * v1.y + v * v2.y,
+                              w * v0.z + u * v1.z + v * v2.z, 1.f);
+          float nx, ny, nz;
+          if (f.s[4] < p.nnormals && f.s[5] < p.nnormals && f.s[6] < p.nnormals) {
+            // u*N[n0] + v*N[n1] + (1-u-v)*N[n2]: the reference's pairing (tracekernel.ck:376)
+            const float4 *np4 = reinterpret_cast<const float4 *>(p.normals);
+            const float4 n0 = np4[f.s[4]], n1 = np4[f.s[5]], n2 = np4[f.s[6]];
+            nx = u * n0.x + v * n1.x + w * n2.x;
+            ny = u * n0.y + v * n1.y + w * n2.y;
+            nz = u * n0.z + v * n1.z + w * n2.z;
+          } else {
+            // no vertex normals in the scene: unit geometric normal
+            const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
+            const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
+            nx = e1y * e2z - e1z * e2y; ny = e1z * e2x - e1x * e2z; nz = e1x * e2y - e1y * e2x;
+            const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+            if (len > 0.f) { nx /= len; ny /= len; nz /= len; }
+          }
+          out_n = make_float4(nx, ny, nz, 0.f);
+          out_d = make_float4(dx, dy, dz, 0.f);
+          out_u = u; out_v = v;
+          if (MODE == kModeTrace) {
+            const uint32_t mi = f.s[3] < p.nmats ? f.s[3] : 0u;
+            if (p.nmats) {
+              const rt_material m = p.mats[mi];
+              const float k = fabsf(nx * dx + ny * dy + nz * dz);
+              color = make_float4(k * m.color.x, k * m.color.y, k * m.color.z, m.Rf);
+            }
+          }
+        }
+        if (p.hits) {
+          float4 *op = reinterpret_cast<float4 *>(p.hits + idx);
+          op[0] = out_o;
+          op[1] = out_d;
+          op[2] = out_n;
+          op[3] = make_float4(out_u, out_v, __uint_as_float(best.id), best.t);
+        }
+      }
+      if (MODE == kModeTrace && p.rgba) reinterpret_cast<float4 *>(p.rgba)[idx] = color;
+    }
+  }
+}
+
+__global__ void TriBatchKernel(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const rt_vec3 a = tri[3 * i], b = tri[3 * i + 1], c = tri[3 * i + 2];
+  RayCtx r;
+  SetupRay(r, ray[i].origin.x, ray[i].origin.y, ray[i].origin.z, ray[i].dir.x, ray[i].dir.y, ray[i].dir.z, 0.f);
+  float tt, u, v;
+  const bool ok = TriTest(a.x, a.y, a.z, b.x - a.x, b.y - a.y, b.z - a.z, c.x - a.x, c.y - a.y, c.z - a.z, r, tt, u, v);
+  hit[i] = ok ? 1 : 0;
+  t[i] = tt;
+  uv[i].u = u;
+  uv[i].v = v;
+}
+
+template <int WIDTH, int MODE, bool PERSISTENT, bool COUNT>
+hipError_t LaunchOne(const KernelArgs &a, uint32_t grid, size_t lds, hipStream_t stream)
+{
+  hipLaunchKernelGGL((ClosestHitKernel<WIDTH, MODE, PERSISTENT, COUNT>), dim3(grid), dim3(256), lds, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t LaunchClosestHit(const KernelArgs &a, int width, int mode, bool persistent, bool count, uint32_t grid,
+                            hipStream_t stream)
+{
+  const size_t lds = static_cast<size_t>(a.stack_entries) * 64u * 4u * 4u;  // entries x lanes x 4 B x 4 waves
+  if (count) {
+    return width == 4 ? LaunchOne<4, kModeIntersect, false, true>(a, grid, lds, stream)
+                      : LaunchOne<2, kModeIntersect, false, true>(a, grid, lds, stream);
+  }
+  if (mode == kModeTrace) {
+    if (persistent)
+      return width == 4 ? LaunchOne<4, kModeTrace, true, false>(a, grid, lds, stream)
+                        : LaunchOne<2, kModeTrace, true, false>(a, grid, lds, stream);
+    return width == 4 ? LaunchOne<4, kModeTrace, false, false>(a, grid, lds, stream)
+                      : LaunchOne<2, kModeTrace, false, false>(a, grid, lds, stream);
+  }
+  if (persistent)
+    return width == 4 ? LaunchOne<4, kModeIntersect, true, false>(a, grid, lds, stream)
+                      : LaunchOne<2, kModeIntersect, true, false>(a, grid, lds, stream);
+  return width == 4 ? LaunchOne<4, kModeIntersect, false, false>(a, grid, lds, stream)
+                    : LaunchOne<2, kModeIntersect, false, false>(a, grid, lds, stream);
+}
+
+hipError_t LaunchTriBatch(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv,
+                          hipStream_t stream)
+{
+  hipLaunchKernelGGL(TriBatchKernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, tri, ray, n, hit, t, uv);
+  return hipGetLastError();
+}
+
+}  // namespace rt

@@ -1,0 +1,105 @@
+// trace_math.h -- the arithmetic shared by the HIP kernels and the host-side
+// fetch counter: per-ray setup, the padded slab test and the closest-hit
+// triangle test.  Compiled with -ffp-contract=off on both sides; the only
+// fused operations are the explicit fmaf() calls in the slab test.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rt {
+
+constexpr float kFltMax = 3.402823466e+38f;
+constexpr float kInvClamp = 1.2676506e30f;         // 2^100: stands in for 1/0
+constexpr float kPadFactor = 7.62939453125e-06f;   // 2^-17 of (|origin|max + scene scale)
+constexpr float kDetEps = 1e-6f;                   // (float)1e-6 = 0x358637BD, just BELOW the double 1e-6
+
+struct RayCtx {
+  float ox, oy, oz;      // origin
+  float dx, dy, dz;      // direction (not renormalised)
+  float ix, iy, iz;      // clamped reciprocal direction
+  float nx, ny, nz;      // -(origin + sgn(d)*pad) * inv : near-plane constant
+  float fx, fy, fz;      // -(origin - sgn(d)*pad) * inv : far-plane constant
+  bool sx, sy, sz;       // direction component negative
+};
+
+RT_HD float SafeInv(float d)
+{
+  float inv = 1.0f / d;
+  // |inv| above 2^100 (including the +-inf of d == 0) and NaN-free clamping.
+  if (!(fabsf(inv) <= kInvClamp)) inv = copysignf(kInvClamp, d);
+  return inv;
+}
+
+// Boxes are tested against planes pushed outward by `pad` = kPadFactor * (max|o| + scale).
+// That margin covers the rounding of the slab arithmetic below and the rounding of the
+// triangle test (whose accepted hits may lie a few ulps of the origin distance outside the
+// exact triangle), so a box holding an accepted hit is never culled.
+RT_HD void SetupRay(RayCtx &r, float ox, float oy, float oz, float dx, float dy, float dz, float scale)
+{
+  r.ox = ox; r.oy = oy; r.oz = oz;
+  r.dx = dx; r.dy = dy; r.dz = dz;
+  r.ix = SafeInv(dx); r.iy = SafeInv(dy); r.iz = SafeInv(dz);
+  r.sx = r.ix < 0.f; r.sy = r.iy < 0.f; r.sz = r.iz < 0.f;
+  const float pad = kPadFactor * (fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + scale);
+  const float px = r.sx ? -pad : pad, py = r.sy ? -pad : pad, pz = r.sz ? -pad : pad;
+  r.nx = -(ox + px) * r.ix; r.ny = -(oy + py) * r.iy; r.nz = -(oz + pz) * r.iz;
+  r.fx = -(ox - px) * r.ix; r.fy = -(oy - py) * r.iy; r.fz = -(oz - pz) * r.iz;
+}
+
+// Entry distance (clamped at 0) of the padded box [lo,hi]; the box is worth visiting
+// iff the returned value <= min(exit distance, tbest) -- inclusive, so a box whose entry
+// equals the best hit so far is still opened and exact ties are resolved by triangle index.
+RT_HD bool SlabTest(const RayCtx &r, float lox, float loy, float loz, float hix, float hiy, float hiz, float tbest,
+                    float &tenter)
+{
+  const float nearx = r.sx ? hix : lox, farx = r.sx ? lox : hix;
+  const float neary = r.sy ? hiy : loy, fary = r.sy ? loy : hiy;
+  const float nearz = r.sz ? hiz : loz, farz = r.sz ? loz : hiz;
+  const float t0x = fmaf(nearx, r.ix, r.nx), t1x = fmaf(farx, r.ix, r.fx);
+  const float t0y = fmaf(neary, r.iy, r.ny), t1y = fmaf(fary, r.iy, r.fy);
+  const float t0z = fmaf(nearz, r.iz, r.nz), t1z = fmaf(farz, r.iz, r.fz);
+  const float tmin = fmaxf(fmaxf(fmaxf(t0x, t0y), t0z), 0.f);
+  const float tmax = fminf(fminf(fminf(t1x, t1y), t1z), tbest);
+  tenter = tmin;
+  return tmin <= tmax;
+}
+
+// Closest-hit triangle test on a pre-gathered record (a, e1 = b - a, e2 = c - a).
+// Operation for operation the reference's core/ray_tri.cpp:20-51 (SUB/CROSS/DOT of
+// core/raydata.h:104-117, DOT summed left to right, 1.f/det a correctly-rounded divide),
+// evaluated without the early returns; the accept conditions are the same predicates in
+// the same sense, so NaNs fall the same way.  NEAR_ZERO(det) and t > EPSILON compare
+// against a DOUBLE 1e-6 in the reference; for float operands those are |det| <= 1e-6f and
+// t > 1e-6f because (float)1e-6 < 1e-6 < nextafterf((float)1e-6, 1).
+RT_HD bool TriTest(float ax, float ay, float az, float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
+                   const RayCtx &r, float &tout, float &uout, float &vout)
+{
+  const float Px = r.dy * e2z - r.dz * e2y;
+  const float Py = r.dz * e2x - r.dx * e2z;
+  const float Pz = r.dx * e2y - r.dy * e2x;
+  const float det = e1x * Px + e1y * Py + e1z * Pz;
+  bool ok = !(fabsf(det) <= kDetEps);
+  const float det_inv = 1.f / det;
+  const float Tx = r.ox - ax, Ty = r.oy - ay, Tz = r.oz - az;
+  const float u = (Tx * Px + Ty * Py + Tz * Pz) * det_inv;
+  ok = ok && !(u < 0.f || u > 1.f);
+  const float Qx = Ty * e1z - Tz * e1y;
+  const float Qy = Tz * e1x - Tx * e1z;
+  const float Qz = Tx * e1y - Ty * e1x;
+  const float v = (r.dx * Qx + r.dy * Qy + r.dz * Qz) * det_inv;
+  ok = ok && !(v < 0.f || v + u > 1.f);
+  const float t = (e2x * Qx + e2y * Qy + e2z * Qz) * det_inv;
+  ok = ok && (t > kDetEps);
+  tout = t; uout = u; vout = v;
+  return ok;
+}
+
+}  // namespace rt
