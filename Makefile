@@ -34,7 +34,7 @@ $(OUT): $(HOST_OBJS) $(HIP_OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -Wl,-rpath,$(ROCM)/lib -lpthread
 
 tools/rt_headless: tools/rt_headless.cpp $(OUT) $(HDRS)
-	$(CXX) -std=c++17 -O2 -Iinclude -o $@ tools/rt_headless.cpp -Lraytrace_amd -lrtamd -Wl,-rpath,'$$ORIGIN/../raytrace_amd' -Wl,-rpath,$(ROCM)/lib
+	$(CXX) -std=c++17 -O2 -Iinclude -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ -o $@ tools/rt_headless.cpp -Lraytrace_amd -lrtamd -L$(ROCM)/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../raytrace_amd' -Wl,-rpath,$(ROCM)/lib
 
 oracle:
 	$(MAKE) -C oracle

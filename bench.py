@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- closest-hit Mrays/s on MI355X.
+
+A "step" is one pass of the hot path (ray_scene_intersection's device form,
+rt_intersect_async) over one batch of rays that is already resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] ...
+
+Workloads (BASELINE.json configs):
+  dragon1080   dragon.obj 1920x1080 primary rays           (default; the headline metric)
+  bunny1080    bunny.obj 1920x1080 primary rays
+  dragon4k     dragon.obj 3840x2160 primary rays
+  ao           bunny_big.obj incoherent AO-style rays (--rays, default 16 Mi per GPU)
+  tiles4k      dragon.obj 3840x2160 split by interleaved 64x64 tiles over the ranks, with the
+               compact framebuffer gathered to rank 0 over RCCL (strong scaling; the gather is
+               timed inside the step and also reported on its own)
+
+With N > 1 (one process per GPU under torch.distributed.run) every rank traces its own
+frame of the workload (rank r's camera is shifted sideways by r steps), so per-GPU work is
+fixed and the job's rays/s is the sum: weak scaling, no data-path collective.  `tiles4k` is
+the sharded-image form with its one exchange step.
+
+Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch / mean
+launch duration (HIP events on the launch stream).  `cpu_baseline` times the CPU oracle
+(brute force over all triangles, the reference's cpu_raycast loop) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # before raytrace_amd: both must bind the same HIP runtime
+
+import raytrace_amd as rt
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+WORKLOADS = {
+    "dragon1080": ("dragon.obj", 1920, 1080),
+    "bunny1080": ("bunny.obj", 1920, 1080),
+    "dragon4k": ("dragon.obj", 3840, 2160),
+    "tiles4k": ("dragon.obj", 3840, 2160),
+    "ao": ("bunny_big.obj", 0, 0),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="dragon1080", choices=sorted(WORKLOADS))
+    ap.add_argument("--width", type=int, default=int(os.environ.get("RT_WIDTH", "0")), help="2 or 4 (0 = library default)")
+    ap.add_argument("--persistent", type=int, default=-1)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--rays", type=int, default=16 * 1024 * 1024, help="ray count for --workload ao")
+    ap.add_argument("--bvh", default="fixed", choices=["fixed", "reference"])
+    ap.add_argument("--out", default="full", choices=["full", "compact"], help="64-byte hit records or 16-byte {id,t,u,v}")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-stride", type=int, default=8, help="sub-grid stride (both axes) of the CPU baseline sample")
+    ap.add_argument("--tile", type=int, default=64)
+    return ap.parse_args()
+
+
+def tile_indices(W, H, tile, rank, world):
+    """Ray indices (row-major i + j*W) of the tiles owned by `rank`: tile k -> rank k % world."""
+    tx, ty = (W + tile - 1) // tile, (H + tile - 1) // tile
+    idx = []
+    for k in range(rank, tx * ty, world):
+        x0, y0 = (k % tx) * tile, (k // tx) * tile
+        xs = np.arange(x0, min(x0 + tile, W))
+        ys = np.arange(y0, min(y0 + tile, H))
+        idx.append((ys[:, None] * W + xs[None, :]).reshape(-1))
+    return np.concatenate(idx) if idx else np.zeros(0, np.int64)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    model, W, H = WORKLOADS[a.workload]
+    mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "tolerant")
+    bvh = rt.BVH(mesh, a.bvh)
+    scene = rt.Scene(mesh, bvh, device=local, width=4 if a.width == 4 else 2)
+    if a.width in (2, 4):
+        scene.set_param("width", a.width)
+    if a.persistent >= 0:
+        scene.set_param("persistent", a.persistent)
+    if a.blocks_per_cu > 0:
+        scene.set_param("blocks_per_cu", a.blocks_per_cu)
+    info = scene.info()
+    box = bvh.root_box
+
+    # ---- synthetic input, generated on the host once, resident in HBM before timing ----
+    if a.workload == "ao":
+        n_local = a.rays
+        rays_h = rt.ao_rays(mesh, box, 1234, rank * n_local, n_local)
+        own = None
+    else:
+        origin = rt.frame_camera(box, W, H)
+        if a.workload == "tiles4k":
+            full = rt.primary_rays(W, H, origin)
+            own = tile_indices(W, H, a.tile, rank, world)
+            rays_h = full[own]
+            del full
+        else:
+            origin[0] += rank * 0.01 * float(box[1, 0] - box[0, 0])  # each rank renders its own frame
+            rays_h = rt.primary_rays(W, H, origin)
+            own = None
+        n_local = len(rays_h)
+    rays_d = torch.from_numpy(rays_h).cuda()
+    full_out = a.out == "full"
+    hits_d = torch.empty((n_local, 16 if full_out else 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    gather_bufs = None
+    if a.workload == "tiles4k" and world > 1:
+        counts = [len(tile_indices(W, H, a.tile, r, world)) for r in range(world)]
+        if rank == 0:
+            gather_bufs = [torch.empty((c, 4), dtype=torch.float32, device="cuda") for c in counts]
+        hits16_d = torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
+
+    def step():
+        if a.workload == "tiles4k" and world > 1:
+            scene.intersect_async(rays_d.data_ptr(), n_local, None, hits16_d.data_ptr(), stream)
+            # one exchange: compact hit tiles to rank 0 (point-to-point sends, not a ring)
+            if rank == 0:
+                gather_bufs[0].copy_(hits16_d)
+                reqs = [dist.irecv(gather_bufs[r], src=r) for r in range(1, world)]
+                for q in reqs:
+                    q.wait()
+            else:
+                dist.isend(hits16_d, dst=0).wait()
+        elif full_out:
+            scene.intersect_async(rays_d.data_ptr(), n_local, hits_d.data_ptr(), None, stream)
+        else:
+            scene.intersect_async(rays_d.data_ptr(), n_local, None, hits_d.data_ptr(), stream)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1) / max(1, a.steps)  # mean launch duration on the launch stream
+    if dist:
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+        nn = torch.tensor([n_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        n_total = int(nn.item())
+    else:
+        n_total = n_local
+    ms_per_step = wall * 1e3 / max(1, a.steps)
+    mrays = n_total / (ms_per_step * 1e-3) / 1e6
+
+    if rank == 0:
+        # ---- algorithmic bytes per ray: records the traversal fetches, counted exactly ----
+        width = a.width if a.width in (2, 4) else 2
+        cnt = scene.count_fetches_device(rays_d.data_ptr(), n_local)
+        stride = max(1, n_local // 8192)
+        cnt_cpu = scene.count_fetches(rays_h, stride)
+        node_b = info["node4_bytes"] if width == 4 else info["node2_bytes"]
+        n_node, n_tri = cnt["nodes"] / cnt["rays"], cnt["tris"] / cnt["rays"]
+        out_b = 64 if (full_out and not (a.workload == "tiles4k" and world > 1)) else 16
+        bytes_per_ray = 64 + out_b + n_node * node_b + n_tri * info["tri_bytes"]
+        achieved = bytes_per_ray * n_local / (dev_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "ClosestHitKernel", "kernel_ms": round(dev_ms, 4), "bytes_per_ray": round(bytes_per_ray, 1),
+            "node_records_per_ray": round(n_node, 3), "tri_records_per_ray": round(n_tri, 3),
+            "node_records_per_ray_cpu_sample": round(cnt_cpu["nodes"] / max(1, cnt_cpu["rays"]), 3),
+            "tri_records_per_ray_cpu_sample": round(cnt_cpu["tris"] / max(1, cnt_cpu["rays"]), 3),
+            "node_bytes": node_b, "tri_bytes": info["tri_bytes"], "ray_in_bytes": 64, "hit_out_bytes": out_b,
+            "hit_fraction": round(cnt["rays_hit"] / cnt["rays"], 4),
+        }
+
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline:
+            import oracle  # the CPU checker, used here only as the timed baseline
+            if a.workload == "ao":
+                sample = rays_h[:: max(1, n_local // 16384)]
+                what = f"{len(sample)} of the {n_local} rays (every {max(1, n_local // 16384)}th)"
+            else:
+                s = a.cpu_stride
+                grid = (np.arange(0, H, s)[:, None] * W + np.arange(0, W, s)[None, :]).reshape(-1)
+                sample = rays_h[grid]
+                what = f"stride-{s} sub-grid of the {W}x{H} ray set ({len(sample)} rays x {len(mesh.faces)} triangles, brute force)"
+            threads = oracle.default_threads()
+            c0 = time.perf_counter()
+            oid, ot, _, _ = oracle.closest_hit(mesh.verts, mesh.faces, sample, threads=threads)
+            cdt = time.perf_counter() - c0
+            # parity spot-check of the same sample against the GPU result of the last step
+            hits_h = hits_d.cpu().numpy()
+            gid = hits_h[:, 14 if full_out else 0].view(np.uint32)
+            sel = grid if a.workload != "ao" else np.arange(0, n_local, max(1, n_local // 16384))
+            mism = int((gid[sel] != oid).sum()) if a.workload != "tiles4k" else None
+            cpu = {"value": round(len(sample) / cdt / 1e6, 6), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                   "sample": what, "seconds": round(cdt, 2), "id_mismatches_vs_gpu": mism}
+
+        line = {
+            "metric": "closest-hit Mrays/s", "value": round(mrays, 1), "unit": "Mrays/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong" if a.workload == "tiles4k" else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{model} {W}x{H} primary rays" if W else f"{model} {n_local} AO rays per GPU",
+                       "name": a.workload, "rays_per_gpu": n_local, "rays_total": n_total, "triangles": len(mesh.faces),
+                       "loader": "tolerant", "bvh": a.bvh, "bvh_width": width, "nodes": info["nodes4" if width == 4 else "nodes2"],
+                       "hit_record": "64B RayIntersection" if out_b == 64 else "16B {id,t,u,v}",
+                       "parallelism": f"{world} x frame-parallel" if a.workload != "tiles4k" else f"{world} x interleaved {a.tile}x{a.tile} tiles + RCCL gather"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

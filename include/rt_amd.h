@@ -87,6 +87,8 @@ int rt_ao_rays(const rt_mesh *m, const rt_aabb *root, uint64_t seed, size_t firs
  * bindings of render_client/img_main.cpp:243-249,293,298-311.  Inputs are copied
  * (the caller keeps ownership); the BVH is validated and re-flattened.  `device` is a
  * HIP device ordinal. */
+#define RT_DEVICE_NONE (-1) /* host-only scene: validation, rt_scene_info and rt_scene_count_fetches work;
+                               every tracing entry point fails with RT_ERR_DEVICE */
 #define RT_SCENE_WIDE2 0u   /* traverse the 64-byte two-child records  */
 #define RT_SCENE_WIDE4 4u   /* traverse the 128-byte four-child records */
 typedef struct rt_scene rt_scene;

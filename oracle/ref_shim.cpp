@@ -54,6 +54,28 @@ size_t ref_bvh_build(const cl_uint8 *tris, const vec3 *verts, size_t ntris, size
   return n;
 }
 
+/* Index-order brute force (the loop shape of cpu_raycast/raycast.cpp:113-122) whose every
+ * triangle test is the reference's intersect_ray_triangle.  hits[k] = {id, t, u, v}. */
+void ref_closest_hit(const vec3 *verts, const cl_uint8 *faces, size_t ntris, const RayIntersection *rays, size_t n,
+                     float *hits)
+{
+  for (size_t k = 0; k < n; ++k) {
+    Ray ray;
+    ray.origin.x = rays[k].origin.s[0]; ray.origin.y = rays[k].origin.s[1]; ray.origin.z = rays[k].origin.s[2]; ray.origin.w = 0;
+    ray.dir.x = rays[k].direction.s[0]; ray.dir.y = rays[k].direction.s[1]; ray.dir.z = rays[k].direction.s[2]; ray.dir.w = 0;
+    float closest = 3.402823466e+38f, bu = 0, bv = 0;
+    unsigned best = 0xFFFFFFFFu;
+    for (size_t mi = 0; mi < ntris; ++mi) {
+      vec2 uv; float dist;
+      if (intersect_ray_triangle(&verts[faces[mi].s[0]], &verts[faces[mi].s[1]], &verts[faces[mi].s[2]], &ray, &uv, &dist)) {
+        if (dist < closest) { closest = dist; best = (unsigned)mi; bu = uv.u; bv = uv.v; }
+      }
+    }
+    std::memcpy(&hits[4 * k], &best, 4);
+    hits[4 * k + 1] = closest; hits[4 * k + 2] = bu; hits[4 * k + 3] = bv;
+  }
+}
+
 void ref_min_size_aabb(AABB *bb) { MinSizeAABB(bb); }
 void ref_centroid(const vec3 *tri3, vec3 *c) { Centroid(reinterpret_cast<Tri const *>(tri3), c); }
 int ref_point_in_aabb(const vec3 *p, const AABB *bb) { return PointInAABB(p, bb) ? 1 : 0; }

@@ -1,0 +1,270 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same rays.
+
+Bar: hit triangle ids bit-exact; t, u, v bit-exact as well (the kernel performs the reference's
+operations in the reference's order with contraction off, so not even the 1e-5 relative tolerance
+the spec allows is needed -- it is asserted at 0 ulp).  Hit point and normal, whose reference
+formula is OpenCL float3 arithmetic with implementation-defined contraction, are held to 1e-5
+relative."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MODELS, ROOT, bits, framed_primary
+from test_oracle import random_pairs
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5  # tolerance for the floating-point outputs that are not bit-pinned (hit point, normal)
+
+
+def compare(rt, oracle, mesh, rays, hits, sel=None):
+    ids, t, u, v = rt.hit_fields(hits)
+    if sel is None:
+        sel = np.arange(len(rays))
+    oid, ot, ou, ov, second = oracle.closest_hit(mesh.verts, mesh.faces, rays[sel], want_second=True)
+    assert np.array_equal(ids[sel], oid), f"{int((ids[sel] != oid).sum())} hit ids differ"
+    h = oid != rt.MISS_ID
+    for mine, ref in ((t, ot), (u, ou), (v, ov)):
+        assert np.array_equal(bits(mine[sel][h]), bits(ref[h]))
+    miss = ~h
+    assert np.all(bits(t[sel][miss]) == 0x7F7FFFFF) and np.all(u[sel][miss] == 0) and np.all(v[sel][miss] == 0)
+    near_ties = int((np.abs(second[h] - ot[h]) <= 1e-6 * np.abs(ot[h])).sum())
+    return int(h.sum()), near_ties
+
+
+@pytest.mark.parametrize("width", [2, 4])
+@pytest.mark.parametrize("persistent", [0, 1])
+@pytest.mark.parametrize("model,loader,W,H,stride", [
+    ("cube.obj", "tolerant", 512, 512, 1),             # exact ties on the shared face diagonals
+    ("cube_mirror_test.obj", "reference", 200, 120, 1),
+    ("teapot.obj", "reference", 160, 128, 1),
+    ("bunny.obj", "tolerant", 1920, 1080, 257),
+    ("dragon.obj", "tolerant", 1920, 1080, 257),
+])
+def test_primary_rays_match_oracle(rt, oracle, gpu, model, loader, W, H, stride, width, persistent):
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, model), loader)
+    bvh = rt.BVH(mesh, "fixed")
+    scene = rt.Scene(mesh, bvh, device=gpu, width=width)
+    scene.set_param("persistent", persistent)
+    rays = framed_primary(rt, bvh, W, H)
+    hits = scene.intersect(rays)
+    sel = None if stride == 1 else np.arange(0, len(rays), stride)
+    nhit, ties = compare(rt, oracle, mesh, rays, hits, sel)
+    assert nhit > 0
+    if model == "cube.obj":
+        assert ties > 0          # the tie rule is really exercised
+    scene.close()
+
+
+def test_reference_bvh_and_reference_loader_give_the_same_hits(rt, oracle, gpu):
+    """The literal reference tree (core/CentroidBVH.cpp:65 as written) is slower, not different."""
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "teapot.obj"), "reference")
+    rays = framed_primary(rt, rt.BVH(mesh, "fixed"), 128, 96)
+    out = []
+    for mode in ("reference", "fixed"):
+        for width in (2, 4):
+            s = rt.Scene(mesh, rt.BVH(mesh, mode), device=gpu, width=width)
+            out.append(s.intersect(rays))
+            s.close()
+    for o in out[1:]:
+        assert np.array_equal(bits(o), bits(out[0]))
+    compare(rt, oracle, mesh, rays, out[0])
+
+
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+@pytest.mark.parametrize("width", [2, 4])
+def test_golden_vectors(rt, gpu, path, width):
+    g = np.load(path)
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, str(g["model"])), str(g["loader"]))
+    scene = rt.Scene(mesh, rt.BVH(mesh, "fixed"), device=gpu, width=width)
+    hits = scene.intersect(rt.primary_rays(int(g["width"]), int(g["height"]), g["origin"]))
+    ids, t, u, v = rt.hit_fields(hits)
+    assert np.array_equal(ids, g["ids"])
+    h = ids != rt.MISS_ID
+    for mine, gold in ((t, g["t"]), (u, g["u"]), (v, g["v"])):
+        assert np.array_equal(bits(mine[h]), bits(gold[h]))
+
+
+def test_kernel_triangle_test_is_bitwise_the_oracle(rt, oracle, gpu):
+    rng = np.random.default_rng(424242)
+    accepted = 0
+    for _ in range(3):
+        tri, ray = random_pairs(rng, 2_000_000)
+        h0, t0, uv0 = oracle.tri_batch(tri, ray)
+        h1, t1, uv1 = rt.debug_tri_batch(tri, ray, device=gpu)
+        assert np.array_equal(h0, h1)
+        m = h0 == 1
+        assert np.array_equal(bits(t0)[m], bits(t1)[m]) and np.array_equal(bits(uv0)[m], bits(uv1)[m])
+        accepted += int(m.sum())
+    assert accepted > 500_000
+
+
+def test_incoherent_rays_match_oracle(rt, oracle, gpu):
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny_big.obj"), "tolerant")
+    bvh = rt.BVH(mesh, "fixed")
+    rays = rt.ao_rays(mesh, bvh.root_box, 1234, 0, 1 << 20)
+    sel = np.arange(0, len(rays), 509)
+    for width in (2, 4):
+        scene = rt.Scene(mesh, bvh, device=gpu, width=width)
+        nhit, _ = compare(rt, oracle, mesh, rays, scene.intersect(rays), sel)
+        assert 0 < nhit < len(sel)
+        scene.close()
+
+
+def test_full_size_properties(rt, gpu):
+    """BASELINE sizes, checked through size-independent properties: the two record layouts and both
+    launch modes agree on every one of the 2 073 600 / 8 294 400 rays, hit records are
+    self-consistent (origin + t*dir lands on the reported hit point, barycentrics inside the
+    triangle), and tracing the hit set again is idempotent."""
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "dragon.obj"), "tolerant")
+    bvh = rt.BVH(mesh, "fixed")
+    for (W, H) in ((1920, 1080), (3840, 2160)):
+        rays = framed_primary(rt, bvh, W, H)
+        ref = None
+        for width, persistent in ((2, 0), (4, 0), (2, 1)):
+            s = rt.Scene(mesh, bvh, device=gpu, width=width)
+            s.set_param("persistent", persistent)
+            hits = s.intersect(rays)
+            s.close()
+            if ref is None:
+                ref = hits
+            else:
+                assert np.array_equal(bits(hits), bits(ref))
+        ids, t, u, v = rt.hit_fields(ref)
+        h = ids != rt.MISS_ID
+        assert 0.3 < h.mean() < 0.45 and ids[h].max() < len(mesh.faces)
+        assert np.all(u[h] >= 0) and np.all(v[h] >= 0) and np.all(u[h] + v[h] <= 1) and np.all(t[h] > 1e-6)
+        p = rays[h, 0:3] + t[h, None] * rays[h, 4:7]
+        scale = np.abs(rays[h, 0:3]).max()
+        err = np.abs(p - ref[h, 0:3]).max(axis=1)
+        # the triangle test's own t is ill-conditioned at grazing incidence, so the tail is loose
+        assert np.median(err) <= 1e-6 * scale and np.quantile(err, 0.999) <= 2e-5 * scale and err.max() <= 1e-3 * scale
+        # miss records carry the reference's defaults (tracekernel.ck:282-286)
+        assert np.array_equal(bits(ref[~h, 0:4]), bits(rays[~h, 0:4])) and np.array_equal(bits(ref[~h, 8:12]), bits(rays[~h, 4:8]))
+
+
+def test_hit_record_fields(rt, oracle, gpu):
+    """Hit point, interpolated normal (the reference's u*N[n0] + v*N[n1] + (1-u-v)*N[n2] pairing,
+    tracekernel.ck:376) and direction, against a float64 numpy restatement, 1e-5 relative."""
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "teapot.obj"), "reference")
+    bvh = rt.BVH(mesh, "fixed")
+    scene = rt.Scene(mesh, bvh, device=gpu)
+    rays = framed_primary(rt, bvh, 96, 96)
+    hits = scene.intersect(rays)
+    ids, t, u, v = rt.hit_fields(hits)
+    h = ids != rt.MISS_ID
+    f = mesh.faces[ids[h]]
+    uu, vv = u[h].astype(np.float64)[:, None], v[h].astype(np.float64)[:, None]
+    ww = 1 - uu - vv
+    V = mesh.verts.astype(np.float64)
+    N = mesh.normals.astype(np.float64)
+    p = ww * V[f[:, 0], :3] + uu * V[f[:, 1], :3] + vv * V[f[:, 2], :3]
+    n = uu * N[f[:, 4], :3] + vv * N[f[:, 5], :3] + ww * N[f[:, 6], :3]
+    assert np.abs(hits[h, 0:3] - p).max() <= REL * np.abs(p).max()
+    assert np.abs(hits[h, 8:11] - n).max() <= REL * max(1.0, np.abs(n).max())
+    assert np.all(hits[h, 3] == 1) and np.all(hits[h, 11] == 0) and np.all(hits[h, 7] == 0)
+    assert np.array_equal(bits(hits[h, 4:7]), bits(rays[h, 4:7]))
+    # a mesh without vn records gets unit geometric normals
+    cube = rt.Mesh.load_obj(os.path.join(MODELS, "cube.obj"), "tolerant")
+    cb = rt.BVH(cube, "fixed")
+    cs = rt.Scene(cube, cb, device=gpu)
+    ch = cs.intersect(framed_primary(rt, cb, 64, 64))
+    hh = ch[:, 14].view(np.uint32) != rt.MISS_ID
+    assert np.allclose(np.linalg.norm(ch[hh, 8:11], axis=1), 1, atol=1e-6)
+
+
+def test_edge_cases(rt, oracle, gpu):
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "cube.obj"), "tolerant")
+    bvh = rt.BVH(mesh, "fixed")
+    for width in (2, 4):
+        scene = rt.Scene(mesh, bvh, device=gpu, width=width)
+        assert scene.intersect(np.zeros((0, 16), np.float32)).shape == (0, 16)          # empty
+        base = framed_primary(rt, bvh, 64, 64)
+        for n in (1, 63, 64, 65, 257):                                                 # ragged sizes
+            compare(rt, oracle, mesh, base[:n], scene.intersect(base[:n]))
+        r = np.zeros((12, 16), np.float32)
+        r[:, 0:3] = (0.5, 0.5, -3)
+        r[0, 4:7] = (0, 0, 1)              # axis-parallel: two zero direction components
+        r[1, 4:7] = (0, 0, -1)             # pointing away
+        r[2, 0:3] = (0.5, 0.5, 0.5); r[2, 4:7] = (0, 1, 0)      # origin inside the cube
+        r[3, 0:3] = (1.0, 0.5, -3); r[3, 4:7] = (0, 0, 1)       # exactly along the x = 1 face
+        r[4, 0:3] = (0.0, 0.0, -3); r[4, 4:7] = (0, 0, 1)       # exactly through a corner edge
+        r[5, 4:7] = (0, 0, 0)              # zero direction
+        r[6, 4:7] = (np.nan, 0, 1)         # NaN direction
+        r[7, 0:3] = (np.nan, 0, 0); r[7, 4:7] = (0, 0, 1)
+        r[8, 4:7] = (0, 0, 1e-30)          # denormal-scale direction
+        r[9, 4:7] = (0, 0, 1e30)
+        r[10, 0:3] = (0.5, 0.5, 0.0); r[10, 4:7] = (0, 0, 1)    # origin on a face: t = 0 is rejected, far face hit
+        r[11, 0:3] = (1e6, 1e6, -1e6); r[11, 4:7] = (-1, -1, 1)  # far-away origin
+        compare(rt, oracle, mesh, r, scene.intersect(r))
+        scene.close()
+    # scenes of <= 4 triangles and coincident triangles
+    sq = rt.Mesh.load_obj(os.path.join(MODELS, "std_square.obj"), "tolerant")
+    sb = rt.BVH(sq, "fixed")
+    ss = rt.Scene(sq, sb, device=gpu)
+    rr = framed_primary(rt, sb, 33, 17)
+    compare(rt, oracle, sq, rr, ss.intersect(rr))
+    verts = np.array([[0, 0, 0, 1], [1, 0, 0, 1], [0, 1, 0, 1]], np.float32)
+    faces = np.zeros((9, 8), np.uint32); faces[:, :3] = (0, 1, 2)
+    co = rt.Mesh.from_arrays(verts, faces)
+    cbv = rt.BVH(co, "fixed")
+    cs = rt.Scene(co, cbv, device=gpu, width=4)
+    rr = framed_primary(rt, cbv, 16, 16)
+    nhit, ties = compare(rt, oracle, co, rr, cs.intersect(rr))
+    assert nhit > 0 and ties == nhit      # nine coincident triangles: index 0 must win every time
+
+
+def test_device_pointers_streams_and_errors(rt, oracle, gpu):
+    import torch
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "teapot.obj"), "reference")
+    bvh = rt.BVH(mesh, "fixed")
+    scene = rt.Scene(mesh, bvh, device=gpu)
+    rays = framed_primary(rt, bvh, 128, 128)
+    want = scene.intersect(rays)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.zeros_like(d_rays)
+    scene.intersect_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr())       # device in, device out
+    assert np.array_equal(bits(d_hits.cpu().numpy()), bits(want))
+    d16 = torch.zeros((len(rays), 4), dtype=torch.float32, device="cuda")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        scene.intersect_async(d_rays.data_ptr(), len(rays), None, d16.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    h16 = d16.cpu().numpy()
+    assert np.array_equal(bits(h16[:, 0]), bits(want[:, 14])) and np.array_equal(bits(h16[:, 1]), bits(want[:, 15]))
+    assert np.array_equal(bits(h16[:, 2:4]), bits(want[:, 12:14]))
+    # host in, device out and the reverse
+    d_hits.zero_()
+    assert rt.lib.ray_scene_intersection(C.c_void_p(rays.ctypes.data), len(rays), scene._h, C.c_void_p(d_hits.data_ptr())) == 0
+    assert np.array_equal(bits(d_hits.cpu().numpy()), bits(want))
+    # errors: message, negative status, nothing aborts
+    assert rt.lib.ray_scene_intersection(None, 5, scene._h, C.c_void_p(d_hits.data_ptr())) == -1
+    assert rt.lib.rt_intersect_async(scene._h, C.c_void_p(d_rays.data_ptr()), 5, None, None, None) == -1
+    h = C.c_void_p()
+    nodes = bvh.nodes
+    assert rt.lib.rt_scene_create(C.c_void_p(mesh.verts.ctypes.data), len(mesh.verts), C.c_void_p(mesh.faces.ctypes.data),
+                                  len(mesh.faces), None, 0, None, 0, C.c_void_p(nodes.ctypes.data), len(nodes),
+                                  99, 0, C.byref(h)) == -3
+    assert rt.lib.rt_scene_create(C.c_void_p(mesh.verts.ctypes.data), len(mesh.verts), C.c_void_p(mesh.faces.ctypes.data),
+                                  len(mesh.faces), None, 0, None, 0, C.c_void_p(nodes.ctypes.data), len(nodes),
+                                  gpu, 3, C.byref(h)) == -1
+
+
+def test_fetch_counters_agree_between_host_and_device(rt, gpu):
+    import torch
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny.obj"), "tolerant")
+    bvh = rt.BVH(mesh, "fixed")
+    rays = framed_primary(rt, bvh, 320, 200)
+    d_rays = torch.from_numpy(rays).cuda()
+    for width in (2, 4):
+        scene = rt.Scene(mesh, bvh, device=gpu, width=width)
+        dev = scene.count_fetches_device(d_rays.data_ptr(), len(rays))
+        host = scene.count_fetches(rays)
+        assert dev == host, (dev, host)
+        scene.close()
