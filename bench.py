@@ -36,6 +36,7 @@ import numpy as np
 import torch  # before raytrace_amd: both must bind the same HIP runtime
 
 import raytrace_amd as rt
+from raytrace_amd.tiles import tile_indices
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
@@ -61,21 +62,9 @@ def parse():
     ap.add_argument("--bvh", default="fixed", choices=["fixed", "reference"])
     ap.add_argument("--out", default="full", choices=["full", "compact"], help="64-byte hit records or 16-byte {id,t,u,v}")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-stride", type=int, default=8, help="sub-grid stride (both axes) of the CPU baseline sample")
+    ap.add_argument("--cpu-stride", type=int, default=4, help="sub-grid stride (both axes) of the CPU baseline sample")
     ap.add_argument("--tile", type=int, default=64)
     return ap.parse_args()
-
-
-def tile_indices(W, H, tile, rank, world):
-    """Ray indices (row-major i + j*W) of the tiles owned by `rank`: tile k -> rank k % world."""
-    tx, ty = (W + tile - 1) // tile, (H + tile - 1) // tile
-    idx = []
-    for k in range(rank, tx * ty, world):
-        x0, y0 = (k % tx) * tile, (k // tx) * tile
-        xs = np.arange(x0, min(x0 + tile, W))
-        ys = np.arange(y0, min(y0 + tile, H))
-        idx.append((ys[:, None] * W + xs[None, :]).reshape(-1))
-    return np.concatenate(idx) if idx else np.zeros(0, np.int64)
 
 
 def main():

@@ -1,0 +1,121 @@
+"""The full `trace` step (render_client/tracekernel.ck:192-414) through rt_trace_pass: camera
+transform (op 0), reflection regeneration (op 1), output record and RGBA32F pixel.
+
+Ray setup is restated in float32 numpy in the same left-to-right unfused order the kernel uses, so
+hit ids and t/u/v stay bit-exact against the brute-force oracle; the colour and the interpolated
+outputs are held to 1e-5 relative (their reference expressions are OpenCL builtins whose rounding is
+implementation-defined)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MODELS, bits, framed_primary
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+f32 = np.float32
+
+
+def dot4(m, v):
+    return ((m[0] * v[:, 0] + m[1] * v[:, 1]) + m[2] * v[:, 2]) + m[3] * v[:, 3]
+
+
+def run_pass(scene, rays_in, cam, op):
+    import torch
+    d_in = torch.from_numpy(np.ascontiguousarray(rays_in)).cuda()
+    d_out = torch.zeros_like(d_in)
+    d_rgba = torch.full((len(rays_in), 4), -1.0, dtype=torch.float32, device="cuda")
+    scene.trace_pass(d_in.data_ptr(), d_out.data_ptr(), d_rgba.data_ptr(), len(rays_in), cam, op)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy(), d_rgba.cpu().numpy()
+
+
+@pytest.mark.parametrize("width", [2, 4])
+def test_primary_then_reflection_pass(rt, oracle, gpu, width):
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "cube_mirror_test.obj"), "reference")
+    bvh = rt.BVH(mesh, "fixed")
+    scene = rt.Scene(mesh, bvh, device=gpu, width=width)
+    W, H = 160, 120
+    # camera table in camera space, placed by the matrix: a rotation about y plus a translation
+    c, s = f32(np.cos(2.6)), f32(np.sin(2.6))   # from the +z side, where the cube sits above the mirror slab
+    box = bvh.root_box
+    centre = 0.5 * (box[0, :3] + box[1, :3])
+    dist = f32(8.0) * f32(np.abs(box[1, :3] - box[0, :3]).max())
+    cam = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], f32)
+    cam[:3, 3] = centre - dist * np.array([s, 0, c], f32)   # eye sits `dist` behind the centre along the view axis
+    rays = rt.primary_rays(W, H, (0, 0, 0))
+    out0, rgba0 = run_pass(scene, rays, cam, 0)
+
+    # ---- op 0: expected world-space rays, float32, same operation order -------------
+    o4 = rays[:, 0:4].copy(); o4[:, 3] = 1
+    d4 = rays[:, 4:8].copy(); d4[:, 3] = 0
+    world = np.zeros_like(rays)
+    for k in range(3):
+        world[:, k] = dot4(cam[k], o4)
+        world[:, 4 + k] = dot4(cam[k], d4)
+    oid, ot, ou, ov = oracle.closest_hit(mesh.verts, mesh.faces, world)
+    ids, t, u, v = rt.hit_fields(out0)
+    assert np.array_equal(ids, oid)
+    h = oid != rt.MISS_ID
+    assert 0.05 < h.mean() < 0.95
+    for a, b in ((t, ot), (u, ou), (v, ov)):
+        assert np.array_equal(bits(a[h]), bits(b[h]))
+    assert np.array_equal(bits(out0[h, 4:7]), bits(world[h, 4:7]))          # direction = transformed dir
+    # miss: record defaults (origin, normal := input direction) and a (0,0,0,0) pixel
+    assert np.array_equal(bits(out0[~h, 0:4]), bits(rays[~h, 0:4])) and np.array_equal(bits(out0[~h, 8:12]), bits(rays[~h, 4:8]))
+    assert np.all(rgba0[~h] == 0)
+    # hit: colour = |n.d| * material.color, alpha = material.Rf
+    f = mesh.faces[ids[h]]
+    n = out0[h, 8:11].astype(np.float64)
+    k = np.abs(np.einsum("ij,ij->i", n, world[h, 4:7].astype(np.float64)))
+    want = np.concatenate([k[:, None] * mesh.materials[f[:, 3], 0:3], mesh.materials[f[:, 3], 9:10]], axis=1)
+    assert np.abs(rgba0[h] - want).max() <= REL * max(1.0, np.abs(want).max())
+    N = mesh.normals.astype(np.float64)
+    uu, vv = u[h].astype(np.float64)[:, None], v[h].astype(np.float64)[:, None]
+    nn = uu * N[f[:, 4], :3] + vv * N[f[:, 5], :3] + (1 - uu - vv) * N[f[:, 6], :3]
+    assert np.abs(n - nn).max() <= REL
+
+    # ---- op 1: reflect the pass-0 records --------------------------------------------
+    out1, rgba1 = run_pass(scene, out0, cam, 1)
+    refl = oracle.reflect_rays(out0)
+    rec = np.zeros_like(out0)
+    rec[:, 0:3] = refl[:, 0:3]
+    rec[:, 4:7] = refl[:, 4:7]
+    rid, rtt, ru, rv = oracle.closest_hit(mesh.verts, mesh.faces, rec)
+    ids1, t1, u1, v1 = rt.hit_fields(out1)
+    live = h
+    assert np.array_equal(ids1[live], rid[live])
+    assert np.all(ids1[~live] == rt.MISS_ID) and np.all(rgba1[~live] == 0)   # terminated rays stay terminated
+    hh = live & (rid != rt.MISS_ID)
+    assert hh.sum() > 0
+    for a, b in ((t1, rtt), (u1, ru), (v1, rv)):
+        assert np.array_equal(bits(a[hh]), bits(b[hh]))
+    assert np.array_equal(bits(out1[hh, 4:7]), bits(refl[hh, 4:7]))
+
+
+def test_identity_camera_equals_plain_intersection(rt, gpu):
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "teapot.obj"), "reference")
+    bvh = rt.BVH(mesh, "fixed")
+    scene = rt.Scene(mesh, bvh, device=gpu)
+    rays = framed_primary(rt, bvh, 128, 80)
+    out, rgba = run_pass(scene, rays, np.eye(4, dtype=f32), 0)
+    plain = scene.intersect(rays)
+    assert np.array_equal(bits(out), bits(plain))
+    h = plain[:, 14].view(np.uint32) != rt.MISS_ID
+    # teapot has no usemtl: every face uses material 0, the all-zero sky material
+    assert np.all(rgba[h, :3] == 0)
+
+
+def test_trace_pass_argument_errors(rt, gpu):
+    import ctypes as C
+    import torch
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "cube.obj"), "tolerant")
+    scene = rt.Scene(mesh, rt.BVH(mesh, "fixed"), device=gpu)
+    buf = torch.zeros((64, 16), dtype=torch.float32, device="cuda")
+    cam = (C.c_float * 16)(*np.eye(4, dtype=f32).reshape(-1))
+    p = C.c_void_p(buf.data_ptr())
+    assert rt.lib.rt_trace_pass(scene._h, p, p, None, 64, cam, 0, None) == -1          # aliasing in/out
+    assert rt.lib.rt_trace_pass(scene._h, p, None, None, 64, cam, 0, None) == -1       # no output at all
+    assert rt.lib.rt_trace_pass(scene._h, p, p, None, 64, cam, 2, None) == -1          # unknown operation
+    assert rt.lib.rt_trace_pass(scene._h, p, None, None, 0, cam, 0, None) == 0         # empty launch is fine

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile_gpu.sh output directory into a short text summary:
+per-kernel time statistics from the kernel trace and per-launch means of every PMC counter for
+the closest-hit kernel."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+KERNEL = "ClosestHitKernel"
+
+
+def rows(pattern):
+    for p in glob.glob(os.path.join(out, pattern), recursive=True):
+        with open(p, newline="") as f:
+            yield from csv.DictReader(f)
+
+
+print("== kernel trace (per kernel: launches, mean/min/max duration in us) ==")
+dur = defaultdict(list)
+for r in rows("trace/**/*kernel_trace.csv"):
+    dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+    print(f"{len(v):6d}  mean {sum(v)/len(v):10.2f}  min {min(v):10.2f}  max {max(v):10.2f}  total {sum(v)/1e3:9.2f} ms  {k[:110]}")
+for r in rows("trace/**/*kernel_trace.csv"):
+    if KERNEL in r["Kernel_Name"]:
+        keys = [k for k in r if any(s in k for s in ("VGPR", "SGPR", "LDS", "Scratch", "Workgroup_Size", "Grid_Size"))]
+        print("launch shape:", {k: r[k] for k in keys})
+        break
+
+print("\n== PMC counters, mean per launch of", KERNEL, "==")
+acc = defaultdict(list)
+for r in rows("pmc_*/**/*counter_collection.csv"):
+    if KERNEL in r.get("Kernel_Name", ""):
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in sorted(acc):
+    v = acc[k]
+    print(f"{k:36s} {sum(v)/len(v):18.1f}   (n={len(v)})")
+m = {k: sum(v) / len(v) for k, v in acc.items()}
+if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+    rd, wr = m["FETCH_SIZE"] * 1024, m["WRITE_SIZE"] * 1024
+    print(f"\nHBM-side bytes per launch: read {rd/1e6:.1f} MB as counted, {2*rd/1e6:.1f} MB with the gfx950 x2 "
+          f"wide-read correction; written {wr/1e6:.1f} MB")
+if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
+    print(f"L2 hit rate: {m['TCC_HIT_sum']/(m['TCC_HIT_sum']+m['TCC_MISS_sum']):.4f}")
+if "SQ_ACTIVE_INST_VALU" in m and "SQ_BUSY_CYCLES" in m:
+    print(f"VALU active / SQ busy cycles: {m['SQ_ACTIVE_INST_VALU']/m['SQ_BUSY_CYCLES']:.4f}")
+if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m:
+    print(f"VALU lane utilisation (thread cycles / (active cycles x 64)): {m['SQ_THREAD_CYCLES_VALU']/(m['SQ_ACTIVE_INST_VALU']*64):.4f}")
