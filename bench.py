@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=4, help="sub-grid stride (both axes) of the CPU baseline sample")
     ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--quant", type=int, default=-1, help="1: 16-bit quantized boxes, 0: float boxes (-1 = library default)")
+    ap.add_argument("--block", type=int, default=0, help="workgroup threads: 64, 128 or 256 (0 = library default)")
+    ap.add_argument("--image-hint", type=int, default=1, help="declare the ray array as a W-wide image (8x8 tiles per wave)")
     return ap.parse_args()
 
 
@@ -91,8 +94,14 @@ def main():
         scene.set_param("width", a.width)
     if a.persistent >= 0:
         scene.set_param("persistent", a.persistent)
+    if a.quant >= 0:
+        scene.set_param("quantized", a.quant)
+    if a.block > 0:
+        scene.set_param("block_threads", a.block)
     if a.blocks_per_cu > 0:
         scene.set_param("blocks_per_cu", a.blocks_per_cu)
+    if W and a.workload != "tiles4k" and a.image_hint:
+        scene.set_param("image_width", W)
     info = scene.info()
     box = bvh.root_box
 

@@ -97,11 +97,17 @@ int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, s
                     const rt_bvh_node *bvh_nodes, size_t nnodes, int device, unsigned flags, rt_scene **out);
 void rt_scene_destroy(rt_scene *s);
 /* info[0..7] = {bvh2 nodes, bvh4 nodes, triangles in leaves, bvh2 depth, bvh4 depth,
- *               bytes per bvh2 node, bytes per bvh4 node, bytes per triangle record} */
+ *               bytes per bvh2 node, bytes per bvh4 node, bytes per triangle record}
+ * (node sizes are those of the layout currently selected by "quantized") */
 int rt_scene_info(const rt_scene *s, uint64_t info[8]);
 /* Tuning knobs: "width" (2 or 4: which record layout the traversal walks), "persistent"
  * (0/1: waves pull rays from a global cursor vs one ray per launched thread),
- * "blocks_per_cu" (resident-workgroup cap of the persistent grid). */
+ * "quantized" (1: records hold 16-bit grid-quantized boxes, 16 bytes per child; 0: float boxes, 32
+ * bytes per child; hits are identical), "block_threads" (64, 128 or 256),
+ * "blocks_per_cu" (resident-workgroup cap of the persistent grid), "image_width" (W > 0 declares
+ * that ray arrays whose length is a multiple of W are row-major W-wide images, as the reference's
+ * 2-D NDRange is, render_client/img_main.cpp:457-461; each wave then takes an 8x8 pixel tile.
+ * Results do not depend on it). */
 int rt_scene_set_param(rt_scene *s, const char *key, int value);
 
 /* ------------------------------------------------------------------ device: the hot path

@@ -82,9 +82,12 @@ struct rt_scene {
   int width = 2;
   int persistent = 0;            // measured on dragon 1080p: hardware dispatch beats a single global ray cursor
   int blocks_per_cu = 8;
+  int quant = 1;                 // traverse the 16-bit quantized records (16 B per child) instead of float boxes
+  int block_threads = 256;       // workgroup size: 64, 128 or 256
+  int image_width = 0;           // hint: ray arrays are row-major images of this width (0 = unstructured)
   rt::FlatScene flat;          // host copy (fetch counting, info)
   size_t nverts = 0, ntris = 0, nnormals = 0, nmats = 0;
-  float4 *d_nodes2 = nullptr, *d_nodes4 = nullptr, *d_tris = nullptr;
+  float4 *d_nodes2 = nullptr, *d_nodes4 = nullptr, *d_nodesq2 = nullptr, *d_nodesq4 = nullptr, *d_tris = nullptr;
   rt_vec3 *d_verts = nullptr;
   rt_face *d_faces = nullptr;
   rt_float4 *d_normals = nullptr;
@@ -102,7 +105,9 @@ namespace {
 void FillArgs(const rt_scene *s, rt::KernelArgs &a)
 {
   std::memset(&a, 0, sizeof a);
-  a.nodes = s->width == 4 ? s->d_nodes4 : s->d_nodes2;
+  if (s->quant) a.nodes = s->width == 4 ? s->d_nodesq4 : s->d_nodesq2;
+  else a.nodes = s->width == 4 ? s->d_nodes4 : s->d_nodes2;
+  for (int k = 0; k < 3; ++k) { a.grid.lo[k] = s->flat.grid_lo[k]; a.grid.step[k] = s->flat.grid_step[k]; }
   a.tris = s->d_tris;
   a.verts = s->d_verts;
   a.faces = s->d_faces;
@@ -118,11 +123,19 @@ void FillArgs(const rt_scene *s, rt::KernelArgs &a)
 // Enqueues one launch over at most 2^30 rays.
 int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStream_t stream)
 {
-  const uint32_t blocks_needed = (a.n + 255u) / 256u;
+  a.img_w = a.img_h = 0;
+  a.ntasks = (a.n + 63u) / 64u;
+  if (s->image_width > 0 && a.n % static_cast<uint32_t>(s->image_width) == 0) {
+    a.img_w = static_cast<uint32_t>(s->image_width);
+    a.img_h = a.n / a.img_w;
+    a.ntasks = ((a.img_w + 7u) / 8u) * ((a.img_h + 7u) / 8u);
+  }
+  const uint32_t block = static_cast<uint32_t>(s->block_threads), wpb = block / 64u;
+  const uint32_t blocks_needed = (a.ntasks + wpb - 1u) / wpb;
   const bool persistent = s->persistent && !count;
   uint32_t grid = blocks_needed;
   if (persistent) {
-    const uint32_t cap = static_cast<uint32_t>(s->num_cu) * static_cast<uint32_t>(s->blocks_per_cu);
+    const uint32_t cap = static_cast<uint32_t>(s->num_cu) * static_cast<uint32_t>(s->blocks_per_cu) * (4u / wpb);
     if (grid > cap) grid = cap;
     const int slot = s->next_counter;
     s->next_counter = (slot + 1) % kCounterSlots;
@@ -131,7 +144,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
   }
   if (static_cast<size_t>(a.stack_entries) * 1024u > 160u * 1024u)
     return Fail(RT_ERR_INVALID, "bvh too deep for the LDS traversal stack");
-  RT_HIP(rt::LaunchClosestHit(a, s->width, mode, persistent, count, grid, stream));
+  RT_HIP(rt::LaunchClosestHit(a, s->width, s->quant != 0, mode, persistent, count, grid, block, stream));
   return RT_OK;
 }
 
@@ -338,6 +351,8 @@ int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, s
   if (rc == RT_OK && hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cu = prop.multiProcessorCount;
   if (rc == RT_OK) rc = Upload(&s->d_nodes2, s->flat.nodes2.data(), s->flat.nodes2.size() * sizeof(rt::GpuNode2));
   if (rc == RT_OK) rc = Upload(&s->d_nodes4, s->flat.nodes4.data(), s->flat.nodes4.size() * sizeof(rt::GpuNode4));
+  if (rc == RT_OK) rc = Upload(&s->d_nodesq2, s->flat.nodesq2.data(), s->flat.nodesq2.size() * sizeof(rt::GpuChildQ));
+  if (rc == RT_OK) rc = Upload(&s->d_nodesq4, s->flat.nodesq4.data(), s->flat.nodesq4.size() * sizeof(rt::GpuChildQ));
   if (rc == RT_OK) rc = Upload(&s->d_tris, s->flat.tris.data(), s->flat.tris.size() * sizeof(rt::GpuTri));
   if (rc == RT_OK) rc = Upload(&s->d_verts, verts, nverts * sizeof(rt_vec3));
   if (rc == RT_OK) rc = Upload(&s->d_faces, faces, ntris * sizeof(rt_face));
@@ -363,7 +378,7 @@ void rt_scene_destroy(rt_scene *s)
     return;
   }
   DeviceGuard guard(s->device);
-  (void)hipFree(s->d_nodes2); (void)hipFree(s->d_nodes4); (void)hipFree(s->d_tris);
+  (void)hipFree(s->d_nodes2); (void)hipFree(s->d_nodes4); (void)hipFree(s->d_nodesq2); (void)hipFree(s->d_nodesq4); (void)hipFree(s->d_tris);
   (void)hipFree(s->d_verts); (void)hipFree(s->d_faces); (void)hipFree(s->d_normals); (void)hipFree(s->d_mats);
   (void)hipFree(s->d_counters); (void)hipFree(s->d_stats);
   (void)hipFree(s->d_stage_in); (void)hipFree(s->d_stage_out);
@@ -375,7 +390,9 @@ int rt_scene_info(const rt_scene *s, uint64_t info[8])
   if (!s || !info) return Fail(RT_ERR_INVALID, "null argument");
   info[0] = s->flat.nodes2.size(); info[1] = s->flat.nodes4.size(); info[2] = s->flat.tris.size();
   info[3] = static_cast<uint64_t>(s->flat.depth2); info[4] = static_cast<uint64_t>(s->flat.depth4);
-  info[5] = sizeof(rt::GpuNode2); info[6] = sizeof(rt::GpuNode4); info[7] = sizeof(rt::GpuTri);
+  info[5] = s->quant ? 2 * sizeof(rt::GpuChildQ) : sizeof(rt::GpuNode2);
+  info[6] = s->quant ? 4 * sizeof(rt::GpuChildQ) : sizeof(rt::GpuNode4);
+  info[7] = sizeof(rt::GpuTri);
   return RT_OK;
 }
 
@@ -388,6 +405,14 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
     s->width = value;
   } else if (k == "persistent") {
     s->persistent = value != 0;
+  } else if (k == "quantized") {
+    s->quant = value != 0;
+  } else if (k == "block_threads") {
+    if (value != 64 && value != 128 && value != 256) return Fail(RT_ERR_INVALID, "block_threads must be 64, 128 or 256");
+    s->block_threads = value;
+  } else if (k == "image_width") {
+    if (value < 0) return Fail(RT_ERR_INVALID, "image_width must be >= 0");
+    s->image_width = value;
   } else if (k == "blocks_per_cu") {
     if (value < 1 || value > 64) return Fail(RT_ERR_INVALID, "blocks_per_cu out of range");
     s->blocks_per_cu = value;
@@ -483,7 +508,7 @@ int rt_scene_count_fetches(const rt_scene *s, const rt_ray_isect *rays_host, siz
 {
   if (!s || !rays_host || !counts) return Fail(RT_ERR_INVALID, "null argument");
   if (stride == 0) stride = 1;
-  rt::FetchCounts fc = rt::CountFetches(s->flat, s->width, rays_host, n, stride);
+  rt::FetchCounts fc = rt::CountFetches(s->flat, s->width, s->quant != 0, rays_host, n, stride);
   counts[0] = fc.nodes; counts[1] = fc.tris; counts[2] = fc.leaves; counts[3] = fc.rays_hit;
   counts[4] = (n + stride - 1) / stride;
   return RT_OK;

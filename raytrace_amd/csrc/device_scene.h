@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #include "../../include/rt_layout.h"
+#include "trace_math.h"
 
 namespace rt {
 
@@ -15,7 +16,8 @@ constexpr int kModeIntersect = 0;  // rays used as given (ray_scene_intersection
 constexpr int kModeTrace = 1;      // full `trace` step: camera / reflection setup + pixel
 
 struct KernelArgs {
-  const float4 *nodes;        // two-wide: 4 float4 per record; four-wide: 8 float4 per record
+  const float4 *nodes;        // float boxes: 4 (two-wide) or 8 (four-wide) float4 per record;
+                              // quantized boxes: one 16-byte child per float4 slot, 2 or 4 per record
   const float4 *tris;         // 3 float4 per record
   const rt_ray_isect *rays;
   rt_ray_isect *hits;         // nullable
@@ -28,16 +30,20 @@ struct KernelArgs {
   uint32_t *counter;          // persistent-wave ray cursor (zeroed before every launch)
   unsigned long long *stats;  // instrumented build only: nodes, tris, leaves, rays hit
   uint32_t n;
+  uint32_t ntasks;            // wave-sized work items: ceil(n/64), or the number of 8x8 tiles
   uint32_t nnormals;
   uint32_t nmats;
   uint32_t stack_entries;     // LDS stack entries per lane
   uint32_t op;                // kModeTrace: 0 = camera transform, 1 = reflect
+  uint32_t img_w;             // > 0: rays are a row-major img_w x img_h image, walked in 8x8 pixel tiles per wave
+  uint32_t img_h;
   float scale;                // max |coordinate| of the scene box (slab padding)
   float cam[16];
+  QuantGrid grid;             // quantized layouts only
 };
 
-hipError_t LaunchClosestHit(const KernelArgs &a, int width, int mode, bool persistent, bool count, uint32_t grid,
-                            hipStream_t stream);
+hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool persistent, bool count,
+                            uint32_t grid, uint32_t block, hipStream_t stream);
 hipError_t LaunchTriBatch(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv,
                           hipStream_t stream);
 

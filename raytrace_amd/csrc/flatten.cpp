@@ -13,11 +13,39 @@
 #include "trace_math.h"
 
 #include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstring>
 
 namespace rt {
 
 namespace {
+
+// Grid index of the plane at or below (down) / at or above (up) coordinate v, with one cell of slack.
+inline uint32_t QuantDown(float v, float lo, float step)
+{
+  double q = std::floor((static_cast<double>(v) - lo) / step);
+  while (q > 0 && lo + q * static_cast<double>(step) > v) q -= 1;
+  q -= 1;
+  return static_cast<uint32_t>(std::min(65535.0, std::max(0.0, q)));
+}
+inline uint32_t QuantUp(float v, float lo, float step)
+{
+  double q = std::ceil((static_cast<double>(v) - lo) / step);
+  while (q < 65535 && lo + q * static_cast<double>(step) < v) q += 1;
+  q += 1;
+  return static_cast<uint32_t>(std::min(65535.0, std::max(0.0, q)));
+}
+
+inline GpuChildQ QuantChild(rt_aabb const &b, uint32_t ref, const float *lo, const float *step)
+{
+  GpuChildQ c;
+  c.x = QuantDown(b.a.x, lo[0], step[0]) | (QuantUp(b.b.x, lo[0], step[0]) << 16);
+  c.y = QuantDown(b.a.y, lo[1], step[1]) | (QuantUp(b.b.y, lo[1], step[1]) << 16);
+  c.z = QuantDown(b.a.z, lo[2], step[2]) | (QuantUp(b.b.z, lo[2], step[2]) << 16);
+  c.ref = ref;
+  return c;
+}
 
 inline float Area(rt_aabb const &b)
 {
@@ -82,8 +110,23 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
 
   auto ref_of = [&](uint32_t node) { return nodes[node].type == RT_BVH_INNER ? inner_id[node] : leaf_ref[node]; };
 
+  // ---- quantization grid over the root box (which spans every vertex) --------------------
+  {
+    const float lo[3] = {nodes[0].aabb.a.x, nodes[0].aabb.a.y, nodes[0].aabb.a.z};
+    const float hi[3] = {nodes[0].aabb.b.x, nodes[0].aabb.b.y, nodes[0].aabb.b.z};
+    for (int k = 0; k < 3; ++k) {
+      out->grid_lo[k] = lo[k];
+      float st = (hi[k] - lo[k]) / 65535.f;
+      if (!(st > 0.f)) st = 1e-6f;
+      // the top plane must reach the box: widen the step until lo + 65535*step >= hi in exact arithmetic
+      while (static_cast<double>(lo[k]) + 65535.0 * st < hi[k]) st = std::nextafter(st, 3.0e38f);
+      out->grid_step[k] = st;
+    }
+  }
+
   // ---- BVH2 records ---------------------------------------------------------------
   out->nodes2.resize(order.size());
+  out->nodesq2.resize(order.size() * 2);
   for (size_t i = 0; i < order.size(); ++i) {
     rt_bvh_node const &n = nodes[order[i]];
     GpuNode2 g;
@@ -95,6 +138,8 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
     g.child[0] = ref_of(c0);
     g.child[1] = ref_of(c1);
     out->nodes2[i] = g;
+    out->nodesq2[2 * i] = QuantChild(b0, g.child[0], out->grid_lo, out->grid_step);
+    out->nodesq2[2 * i + 1] = QuantChild(b1, g.child[1], out->grid_lo, out->grid_step);
   }
   out->depth2 = max_depth;
   out->stack2 = max_depth + 1;
@@ -144,6 +189,7 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
       nk.push_back(n);
     }
     out->nodes4.resize(roots.size());
+    out->nodesq4.resize(roots.size() * 4);
     for (size_t i = 0; i < roots.size(); ++i) {
       GpuNode4 g;
       std::memset(&g, 0, sizeof g);
@@ -153,10 +199,12 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
           g.lox[k] = b.a.x; g.loy[k] = b.a.y; g.loz[k] = b.a.z;
           g.hix[k] = b.b.x; g.hiy[k] = b.b.y; g.hiz[k] = b.b.z;
           g.child[k] = nodes[kids[i][k]].type == RT_BVH_INNER ? id4[kids[i][k]] : leaf_ref[kids[i][k]];
+          out->nodesq4[4 * i + k] = QuantChild(b, g.child[k], out->grid_lo, out->grid_step);
         } else {  // unused slot: inverted box never passes the slab test
           g.lox[k] = g.loy[k] = g.loz[k] = kFltMax;
           g.hix[k] = g.hiy[k] = g.hiz[k] = -kFltMax;
           g.child[k] = kEmptyRef;
+          out->nodesq4[4 * i + k] = GpuChildQ{0x0000FFFFu, 0x0000FFFFu, 0x0000FFFFu, kEmptyRef};
         }
       }
       out->nodes4[i] = g;
@@ -176,8 +224,11 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
 }
 
 // Host mirror of the device traversal (same order, same arithmetic) that only counts.
-FetchCounts CountFetches(FlatScene const &fs, int width, rt_ray_isect const *rays, size_t nrays, size_t stride)
+FetchCounts CountFetches(FlatScene const &fs, int width, bool quant, rt_ray_isect const *rays, size_t nrays,
+                         size_t stride)
 {
+  QuantGrid grid;
+  for (int k = 0; k < 3; ++k) { grid.lo[k] = fs.grid_lo[k]; grid.step[k] = fs.grid_step[k]; }
   FetchCounts fc;
   if (stride == 0) stride = 1;
   std::vector<uint32_t> stack(static_cast<size_t>(std::max(fs.stack2, fs.stack4)) + 8);
@@ -185,6 +236,8 @@ FetchCounts CountFetches(FlatScene const &fs, int width, rt_ray_isect const *ray
     RayCtx r;
     SetupRay(r, rays[k].origin.x, rays[k].origin.y, rays[k].origin.z, rays[k].direction.x, rays[k].direction.y,
              rays[k].direction.z, fs.scale);
+    RayCtxQ rq;
+    SetupRayQ(rq, r, grid, fs.scale);
     float tbest = kFltMax;
     uint32_t best = 0xFFFFFFFFu;
     size_t sp = 0;
@@ -195,7 +248,17 @@ FetchCounts CountFetches(FlatScene const &fs, int width, rt_ray_isect const *ray
         uint32_t hit_ref[4];
         float hit_t[4];
         int nh = 0;
-        if (width == 4) {
+        if (quant) {
+          const int w = width == 4 ? 4 : 2;
+          GpuChildQ const *c = (w == 4 ? fs.nodesq4.data() : fs.nodesq2.data()) + static_cast<size_t>(cur) * w;
+          for (int i = 0; i < w; ++i) {
+            float te;
+            if (SlabTestQ(rq, c[i].x, c[i].y, c[i].z, tbest, te)) {
+              hit_ref[nh] = c[i].ref;
+              hit_t[nh++] = te;
+            }
+          }
+        } else if (width == 4) {
           GpuNode4 const &n = fs.nodes4[cur];
           for (int c = 0; c < 4; ++c) {
             float te;

@@ -112,9 +112,19 @@ struct GpuNode4 {
 };
 static_assert(sizeof(GpuNode4) == 128, "BVH4 node is 128 B");
 
+// One child of a quantized node: three axis words (lo | hi << 16 on the scene grid) + reference.
+struct GpuChildQ {
+  uint32_t x, y, z, ref;
+};
+static_assert(sizeof(GpuChildQ) == 16, "quantized child is 16 B");
+
 struct FlatScene {
   std::vector<GpuNode2> nodes2;
   std::vector<GpuNode4> nodes4;
+  std::vector<GpuChildQ> nodesq2;  // 2 children per record (32 B), same indexing as nodes2
+  std::vector<GpuChildQ> nodesq4;  // 4 children per record (64 B), same indexing as nodes4
+  float grid_lo[3] = {0, 0, 0};    // quantization grid: plane(q) = grid_lo + q * grid_step
+  float grid_step[3] = {1, 1, 1};
   std::vector<GpuTri> tris;
   int depth2 = 0;       // max number of inner nodes on a root-to-leaf path (BVH2)
   int depth4 = 0;       // same for the collapsed BVH4
@@ -132,7 +142,8 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
 // Host traversal of the flattened layouts, used ONLY to count records fetched per ray
 // (the algorithmic-bytes figure); it returns counters, never hits.
 struct FetchCounts { uint64_t nodes = 0, tris = 0, leaves = 0, rays_hit = 0, max_stack = 0; };
-FetchCounts CountFetches(FlatScene const &fs, int width, rt_ray_isect const *rays, size_t nrays, size_t stride);
+FetchCounts CountFetches(FlatScene const &fs, int width, bool quant, rt_ray_isect const *rays, size_t nrays,
+                         size_t stride);
 
 // ---- framebuffer output (cpu_raycast/bmp.c:6-56 byte layout) ---------------
 bool WriteBmp32(const char *path, const uint8_t *bgra, int width, int height);

@@ -115,9 +115,62 @@ __device__ __forceinline__ uint32_t Step4(const KernelArgs &p, const RayCtx &r, 
   return next;
 }
 
+// Quantized records: WIDTH children of 16 bytes each {x, y, z axis words, reference}.
+__device__ __forceinline__ uint32_t Step2Q(const KernelArgs &p, const RayCtxQ &q, uint32_t cur, float tbest,
+                                           uint32_t *stk, uint32_t &sp)
+{
+  const uint4 *np = reinterpret_cast<const uint4 *>(p.nodes) + static_cast<size_t>(cur) * 2u;
+  const uint4 c0 = np[0], c1 = np[1];
+  float t0, t1;
+  const bool h0 = SlabTestQ(q, c0.x, c0.y, c0.z, tbest, t0);
+  const bool h1 = SlabTestQ(q, c1.x, c1.y, c1.z, tbest, t1);
+  if (h0 && h1) {
+    const bool swap = t1 < t0;
+    stk[sp * 64u] = swap ? c0.w : c1.w;
+    sp++;
+    return swap ? c1.w : c0.w;
+  }
+  if (h0) return c0.w;
+  if (h1) return c1.w;
+  if (sp == 0) return kDone;
+  return stk[--sp * 64u];
+}
+
+__device__ __forceinline__ uint32_t Step4Q(const KernelArgs &p, const RayCtxQ &q, uint32_t cur, float tbest,
+                                           uint32_t *stk, uint32_t &sp)
+{
+  const uint4 *np = reinterpret_cast<const uint4 *>(p.nodes) + static_cast<size_t>(cur) * 4u;
+  const uint4 c0 = np[0], c1 = np[1], c2 = np[2], c3 = np[3];
+  float t0, t1, t2, t3;
+  const bool h0 = SlabTestQ(q, c0.x, c0.y, c0.z, tbest, t0);
+  const bool h1 = SlabTestQ(q, c1.x, c1.y, c1.z, tbest, t1);
+  const bool h2 = SlabTestQ(q, c2.x, c2.y, c2.z, tbest, t2);
+  const bool h3 = SlabTestQ(q, c3.x, c3.y, c3.z, tbest, t3);
+  const uint32_t nh = uint32_t(h0) + uint32_t(h1) + uint32_t(h2) + uint32_t(h3);
+  if (nh == 0) {
+    if (sp == 0) return kDone;
+    return stk[--sp * 64u];
+  }
+  const uint32_t r0 = uint32_t(h1 && t1 < t0) + uint32_t(h2 && t2 < t0) + uint32_t(h3 && t3 < t0);
+  const uint32_t r1 = uint32_t(h0 && t0 <= t1) + uint32_t(h2 && t2 < t1) + uint32_t(h3 && t3 < t1);
+  const uint32_t r2 = uint32_t(h0 && t0 <= t2) + uint32_t(h1 && t1 <= t2) + uint32_t(h3 && t3 < t2);
+  const uint32_t r3 = uint32_t(h0 && t0 <= t3) + uint32_t(h1 && t1 <= t3) + uint32_t(h2 && t2 <= t3);
+  const uint32_t top = sp + nh - 1u;
+  if (h0 && r0) stk[(top - r0) * 64u] = c0.w;
+  if (h1 && r1) stk[(top - r1) * 64u] = c1.w;
+  if (h2 && r2) stk[(top - r2) * 64u] = c2.w;
+  if (h3 && r3) stk[(top - r3) * 64u] = c3.w;
+  sp = top;
+  uint32_t next = c3.w;
+  if (h2 && r2 == 0) next = c2.w;
+  if (h1 && r1 == 0) next = c1.w;
+  if (h0 && r0 == 0) next = c0.w;
+  return next;
+}
+
 __device__ __forceinline__ float Dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-template <int WIDTH, int MODE, bool PERSISTENT, bool COUNT>
+template <int WIDTH, bool QUANT, int MODE, bool PERSISTENT, bool COUNT>
 __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
 {
   extern __shared__ uint32_t lds_stack[];
@@ -131,12 +184,22 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
       if (lane == 0) got = atomicAdd(p.counter, 64u);
       base = __builtin_amdgcn_readfirstlane(got);
     } else {
-      base = (blockIdx.x * 4u + wave) * 64u;
+      base = (blockIdx.x * (blockDim.x >> 6) + wave) * 64u;
       if (round) break;
     }
-    if (base >= p.n) break;
-    const uint32_t idx = base + lane;
-    if (idx < p.n) {
+    if (base >= p.ntasks * 64u) break;
+    // Ray owned by this lane.  Linear: 64 consecutive records per wave.  Image: the wave covers an
+    // 8x8 pixel tile (the reference launches 8x8 work-groups too, img_main.cpp:457-461), which keeps
+    // the 64 rays of a wave on neighbouring paths through the tree.
+    uint32_t idx = base + lane;
+    bool valid = idx < p.n;
+    if (p.img_w) {
+      const uint32_t tiles_x = (p.img_w + 7u) >> 3, task = base >> 6;
+      const uint32_t x = (task % tiles_x) * 8u + (lane & 7u), y = (task / tiles_x) * 8u + (lane >> 3);
+      valid = x < p.img_w && y < p.img_h;
+      idx = y * p.img_w + x;
+    }
+    if (valid) {
       const float4 *rp = reinterpret_cast<const float4 *>(p.rays + idx);
       const float4 in_o = LoadF4(rp), in_d = LoadF4(rp + 1);
       float ox = in_o.x, oy = in_o.y, oz = in_o.z, dx = in_d.x, dy = in_d.y, dz = in_d.z;
@@ -163,6 +226,8 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
 
       RayCtx r;
       SetupRay(r, ox, oy, oz, dx, dy, dz, p.scale);
+      RayCtxQ rq;
+      if (QUANT) SetupRayQ(rq, r, p.grid, p.scale);
       Best best{kFltMax, 0.f, 0.f, RT_MISS_ID};
       uint32_t sp = 0, cur = live ? 0u : kDone;
       uint32_t nnode = 0, ntri = 0, nleaf = 0;
@@ -171,7 +236,10 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
         // descend through inner records until this lane holds a leaf (or runs dry)
         while (!(cur & kLeafBitDev)) {
           if (COUNT) nnode++;
-          cur = (WIDTH == 4) ? Step4(p, r, cur, best.t, stk, sp) : Step2(p, r, cur, best.t, stk, sp);
+          if (QUANT)
+            cur = (WIDTH == 4) ? Step4Q(p, rq, cur, best.t, stk, sp) : Step2Q(p, rq, cur, best.t, stk, sp);
+          else
+            cur = (WIDTH == 4) ? Step4(p, r, cur, best.t, stk, sp) : Step2(p, r, cur, best.t, stk, sp);
         }
         if (cur != kDone) {
           if (COUNT) nleaf += (cur & 7u) ? 1u : 0u;
@@ -266,35 +334,36 @@ __global__ void TriBatchKernel(const rt_vec3 *tri, const rt_ray *ray, uint32_t n
   uv[i].v = v;
 }
 
-template <int WIDTH, int MODE, bool PERSISTENT, bool COUNT>
-hipError_t LaunchOne(const KernelArgs &a, uint32_t grid, size_t lds, hipStream_t stream)
+template <int WIDTH, bool QUANT, int MODE, bool PERSISTENT, bool COUNT>
+hipError_t LaunchOne(const KernelArgs &a, uint32_t grid, uint32_t block, size_t lds, hipStream_t stream)
 {
-  hipLaunchKernelGGL((ClosestHitKernel<WIDTH, MODE, PERSISTENT, COUNT>), dim3(grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((ClosestHitKernel<WIDTH, QUANT, MODE, PERSISTENT, COUNT>), dim3(grid), dim3(block), lds, stream, a);
   return hipGetLastError();
+}
+
+template <int WIDTH, bool QUANT>
+hipError_t LaunchLayout(const KernelArgs &a, int mode, bool persistent, bool count, uint32_t grid, uint32_t block,
+                        size_t lds, hipStream_t stream)
+{
+  if (count) return LaunchOne<WIDTH, QUANT, kModeIntersect, false, true>(a, grid, block, lds, stream);
+  if (mode == kModeTrace)
+    return persistent ? LaunchOne<WIDTH, QUANT, kModeTrace, true, false>(a, grid, block, lds, stream)
+                      : LaunchOne<WIDTH, QUANT, kModeTrace, false, false>(a, grid, block, lds, stream);
+  return persistent ? LaunchOne<WIDTH, QUANT, kModeIntersect, true, false>(a, grid, block, lds, stream)
+                    : LaunchOne<WIDTH, QUANT, kModeIntersect, false, false>(a, grid, block, lds, stream);
 }
 
 }  // namespace
 
-hipError_t LaunchClosestHit(const KernelArgs &a, int width, int mode, bool persistent, bool count, uint32_t grid,
-                            hipStream_t stream)
+hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool persistent, bool count,
+                            uint32_t grid, uint32_t block, hipStream_t stream)
 {
-  const size_t lds = static_cast<size_t>(a.stack_entries) * 64u * 4u * 4u;  // entries x lanes x 4 B x 4 waves
-  if (count) {
-    return width == 4 ? LaunchOne<4, kModeIntersect, false, true>(a, grid, lds, stream)
-                      : LaunchOne<2, kModeIntersect, false, true>(a, grid, lds, stream);
-  }
-  if (mode == kModeTrace) {
-    if (persistent)
-      return width == 4 ? LaunchOne<4, kModeTrace, true, false>(a, grid, lds, stream)
-                        : LaunchOne<2, kModeTrace, true, false>(a, grid, lds, stream);
-    return width == 4 ? LaunchOne<4, kModeTrace, false, false>(a, grid, lds, stream)
-                      : LaunchOne<2, kModeTrace, false, false>(a, grid, lds, stream);
-  }
-  if (persistent)
-    return width == 4 ? LaunchOne<4, kModeIntersect, true, false>(a, grid, lds, stream)
-                      : LaunchOne<2, kModeIntersect, true, false>(a, grid, lds, stream);
-  return width == 4 ? LaunchOne<4, kModeIntersect, false, false>(a, grid, lds, stream)
-                    : LaunchOne<2, kModeIntersect, false, false>(a, grid, lds, stream);
+  const size_t lds = static_cast<size_t>(a.stack_entries) * 4u * block;  // entries x 4 B x lanes of the workgroup
+  if (width == 4)
+    return quant ? LaunchLayout<4, true>(a, mode, persistent, count, grid, block, lds, stream)
+                 : LaunchLayout<4, false>(a, mode, persistent, count, grid, block, lds, stream);
+  return quant ? LaunchLayout<2, true>(a, mode, persistent, count, grid, block, lds, stream)
+               : LaunchLayout<2, false>(a, mode, persistent, count, grid, block, lds, stream);
 }
 
 hipError_t LaunchTriBatch(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv,

@@ -72,6 +72,59 @@ RT_HD bool SlabTest(const RayCtx &r, float lox, float loy, float loz, float hix,
   return tmin <= tmax;
 }
 
+// ---- 16-bit quantized boxes -------------------------------------------------------------
+// A child box is three dwords, one per axis, lo in the low half and hi in the high half, on a
+// uniform 65536-step grid over the scene box: plane(q) = grid_lo + q * step, lo rounded down and
+// hi rounded up on the host, so the decoded box always contains the float box.  A child costs
+// 16 bytes (three dwords + reference) instead of 28, which halves the record fetches the texture
+// path has to serve per traversal step.  The slab distances come straight from the grid indices:
+//   t = (grid_lo + q*step - o') * inv = q * (step*inv) + (grid_lo - o') * inv = fma(q, A, B)
+// with A and B per-ray constants; the rounding of A, B and the fma is covered by the same outward
+// padding of o' that SetupRay applies.
+struct QuantGrid {
+  float lo[3];
+  float step[3];
+};
+
+struct RayCtxQ {
+  float ax, ay, az;        // step * inv
+  float bnx, bny, bnz;     // (grid_lo - (o + sgn*pad)) * inv : near planes
+  float bfx, bfy, bfz;     // (grid_lo - (o - sgn*pad)) * inv : far planes
+  uint32_t rx, ry, rz;     // 16 if the direction component is negative (near plane = hi half), else 0
+};
+
+RT_HD void SetupRayQ(RayCtxQ &q, const RayCtx &r, const QuantGrid &g, float scale)
+{
+  const float pad = kPadFactor * (fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz)) + scale);
+  const float px = r.sx ? -pad : pad, py = r.sy ? -pad : pad, pz = r.sz ? -pad : pad;
+  q.ax = g.step[0] * r.ix; q.ay = g.step[1] * r.iy; q.az = g.step[2] * r.iz;
+  q.bnx = (g.lo[0] - (r.ox + px)) * r.ix; q.bny = (g.lo[1] - (r.oy + py)) * r.iy; q.bnz = (g.lo[2] - (r.oz + pz)) * r.iz;
+  q.bfx = (g.lo[0] - (r.ox - px)) * r.ix; q.bfy = (g.lo[1] - (r.oy - py)) * r.iy; q.bfz = (g.lo[2] - (r.oz - pz)) * r.iz;
+  q.rx = r.sx ? 16u : 0u; q.ry = r.sy ? 16u : 0u; q.rz = r.sz ? 16u : 0u;
+}
+
+RT_HD uint32_t Rot32(uint32_t v, uint32_t s)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(v, v, s);
+#else
+  return s ? ((v >> s) | (v << (32u - s))) : v;
+#endif
+}
+
+// cx, cy, cz: the three packed axis words of one child.  Same acceptance rule as SlabTest.
+RT_HD bool SlabTestQ(const RayCtxQ &q, uint32_t cx, uint32_t cy, uint32_t cz, float tbest, float &tenter)
+{
+  const uint32_t wx = Rot32(cx, q.rx), wy = Rot32(cy, q.ry), wz = Rot32(cz, q.rz);  // low half = near plane
+  const float t0x = fmaf(static_cast<float>(wx & 0xFFFFu), q.ax, q.bnx), t1x = fmaf(static_cast<float>(wx >> 16), q.ax, q.bfx);
+  const float t0y = fmaf(static_cast<float>(wy & 0xFFFFu), q.ay, q.bny), t1y = fmaf(static_cast<float>(wy >> 16), q.ay, q.bfy);
+  const float t0z = fmaf(static_cast<float>(wz & 0xFFFFu), q.az, q.bnz), t1z = fmaf(static_cast<float>(wz >> 16), q.az, q.bfz);
+  const float tmin = fmaxf(fmaxf(fmaxf(t0x, t0y), t0z), 0.f);
+  const float tmax = fminf(fminf(fminf(t1x, t1y), t1z), tbest);
+  tenter = tmin;
+  return tmin <= tmax;
+}
+
 // Closest-hit triangle test on a pre-gathered record (a, e1 = b - a, e2 = c - a).
 // Operation for operation the reference's core/ray_tri.cpp:20-51 (SUB/CROSS/DOT of
 // core/raydata.h:104-117, DOT summed left to right, 1.f/det a correctly-rounded divide),

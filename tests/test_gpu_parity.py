@@ -36,7 +36,7 @@ def compare(rt, oracle, mesh, rays, hits, sel=None):
 
 
 @pytest.mark.parametrize("width", [2, 4])
-@pytest.mark.parametrize("persistent", [0, 1])
+@pytest.mark.parametrize("persistent,quant", [(0, 1), (1, 1), (0, 0)])
 @pytest.mark.parametrize("model,loader,W,H,stride", [
     ("cube.obj", "tolerant", 512, 512, 1),             # exact ties on the shared face diagonals
     ("cube_mirror_test.obj", "reference", 200, 120, 1),
@@ -44,11 +44,14 @@ def compare(rt, oracle, mesh, rays, hits, sel=None):
     ("bunny.obj", "tolerant", 1920, 1080, 257),
     ("dragon.obj", "tolerant", 1920, 1080, 257),
 ])
-def test_primary_rays_match_oracle(rt, oracle, gpu, model, loader, W, H, stride, width, persistent):
+def test_primary_rays_match_oracle(rt, oracle, gpu, model, loader, W, H, stride, width, persistent, quant):
     mesh = rt.Mesh.load_obj(os.path.join(MODELS, model), loader)
     bvh = rt.BVH(mesh, "fixed")
     scene = rt.Scene(mesh, bvh, device=gpu, width=width)
     scene.set_param("persistent", persistent)
+    scene.set_param("quantized", quant)
+    if W % 8 == 0:
+        scene.set_param("image_width", W)
     rays = framed_primary(rt, bvh, W, H)
     hits = scene.intersect(rays)
     sel = None if stride == 1 else np.arange(0, len(rays), stride)
@@ -127,9 +130,11 @@ def test_full_size_properties(rt, gpu):
     for (W, H) in ((1920, 1080), (3840, 2160)):
         rays = framed_primary(rt, bvh, W, H)
         ref = None
-        for width, persistent in ((2, 0), (4, 0), (2, 1)):
+        for width, persistent, quant, hint in ((2, 0, 1, 0), (4, 0, 1, W), (2, 1, 1, W), (2, 0, 0, W), (4, 0, 0, 0)):
             s = rt.Scene(mesh, bvh, device=gpu, width=width)
             s.set_param("persistent", persistent)
+            s.set_param("quantized", quant)
+            s.set_param("image_width", hint)
             hits = s.intersect(rays)
             s.close()
             if ref is None:
@@ -188,6 +193,11 @@ def test_edge_cases(rt, oracle, gpu):
         base = framed_primary(rt, bvh, 64, 64)
         for n in (1, 63, 64, 65, 257):                                                 # ragged sizes
             compare(rt, oracle, mesh, base[:n], scene.intersect(base[:n]))
+        for (w, h) in ((70, 45), (8, 8), (9, 1), (1, 9), (64, 3)):                      # images that do not tile by 8x8
+            scene.set_param("image_width", w)
+            img = framed_primary(rt, bvh, w, h)
+            compare(rt, oracle, mesh, img, scene.intersect(img))
+        scene.set_param("image_width", 0)
         r = np.zeros((12, 16), np.float32)
         r[:, 0:3] = (0.5, 0.5, -3)
         r[0, 4:7] = (0, 0, 1)              # axis-parallel: two zero direction components
@@ -264,7 +274,9 @@ def test_fetch_counters_agree_between_host_and_device(rt, gpu):
     d_rays = torch.from_numpy(rays).cuda()
     for width in (2, 4):
         scene = rt.Scene(mesh, bvh, device=gpu, width=width)
-        dev = scene.count_fetches_device(d_rays.data_ptr(), len(rays))
-        host = scene.count_fetches(rays)
-        assert dev == host, (dev, host)
+        for quant in (1, 0):
+            scene.set_param("quantized", quant)
+            dev = scene.count_fetches_device(d_rays.data_ptr(), len(rays))
+            host = scene.count_fetches(rays)
+            assert dev == host, (quant, dev, host)
         scene.close()
