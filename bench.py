@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=4, help="sub-grid stride (both axes) of the CPU baseline sample")
     ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--extra-stack", type=int, default=0, help="diagnostic: extra LDS per lane to lower occupancy")
     ap.add_argument("--quant", type=int, default=-1, help="1: 16-bit quantized boxes, 0: float boxes (-1 = library default)")
     ap.add_argument("--block", type=int, default=0, help="workgroup threads: 64, 128 or 256 (0 = library default)")
     ap.add_argument("--image-hint", type=int, default=1, help="declare the ray array as a W-wide image (8x8 tiles per wave)")
@@ -94,6 +95,8 @@ def main():
         scene.set_param("width", a.width)
     if a.persistent >= 0:
         scene.set_param("persistent", a.persistent)
+    if a.extra_stack > 0:
+        scene.set_param("extra_stack", a.extra_stack)
     if a.quant >= 0:
         scene.set_param("quantized", a.quant)
     if a.block > 0:

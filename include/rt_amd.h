@@ -104,7 +104,11 @@ int rt_scene_info(const rt_scene *s, uint64_t info[8]);
  * (0/1: waves pull rays from a global cursor vs one ray per launched thread),
  * "quantized" (1: records hold 16-bit grid-quantized boxes, 16 bytes per child; 0: float boxes, 32
  * bytes per child; hits are identical), "block_threads" (64, 128 or 256),
- * "blocks_per_cu" (resident-workgroup cap of the persistent grid), "image_width" (W > 0 declares
+ * "feedback" (1: each launch bins its work units by measured traversal cost and the next launch of the same
+ * shape on this scene starts the costliest bins first -- a schedule only, every ray is traced every time;
+ * launches of one scene must then be issued on one stream at a time), "centre_first" (image mode: 1 dispatches the tiles nearest the image centre first, 0 in row order),
+ * "leaf_pct" (1..100: a wave switches from node steps to leaf steps once this share of its busy lanes holds a
+ * leaf; 100 = descend until every lane does), "blocks_per_cu" (resident-workgroup cap of the persistent grid), "image_width" (W > 0 declares
  * that ray arrays whose length is a multiple of W are row-major W-wide images, as the reference's
  * 2-D NDRange is, render_client/img_main.cpp:457-461; each wave then takes an 8x8 pixel tile.
  * Results do not depend on it). */
@@ -138,12 +142,28 @@ int rt_trace_pass(const rt_scene *scene, const void *rays_in_dev, void *rays_out
 
 /* Mean records fetched per ray by the traversal, counted on the host over rays
  * 0, stride, 2*stride, ... : counts[0..4] = {node records, triangle records, non-empty
- * leaves, rays that hit, rays counted}.  A measurement aid; computes no hits. */
+ * leaves, rays that hit, rays counted}.  per_ray (nullable, 2 x rays-counted uint32) receives each counted
+ * ray's own {node records, triangle records}.  A measurement aid; computes no hits. */
 int rt_scene_count_fetches(const rt_scene *s, const rt_ray_isect *rays_host, size_t n, size_t stride,
-                           uint64_t counts[5]);
+                           uint64_t counts[5], uint32_t *per_ray);
+/* Planning aid: a host-side lockstep model of one 64-lane wave running the traversal (a phase lasts as
+ * long as its slowest lane).  Samples `max_waves` waves (0 = all) over the ray stream and returns
+ * out[0..9] = {waves, rays, wave node steps, useful lane node steps, wave triangle steps, useful lane
+ * triangle steps, wave leaf phases, lanes in leaf phases, refill events, lanes refilled, steps of the longest
+ * wave}.  policy 0 = descend until every lane holds a leaf, then test leaves; 1 = one node step and one
+ * leaf test per iteration.  refill = 0
+ * models one batch of 64 rays per wave; refill = k models a wave that takes new rays for its idle
+ * lanes whenever k or more lanes have finished.  Computes no hits. */
+int rt_scene_wave_model(const rt_scene *s, const rt_ray_isect *rays_host, size_t n, unsigned image_width, unsigned refill,
+                        size_t max_waves, int policy, uint64_t out[11]);
 /* The same counters taken on the device by an instrumented build of the kernel over all n
  * rays (device pointer): counts[0..3] as above, counts[4] = n. */
 int rt_scene_count_fetches_device(const rt_scene *s, const void *rays_dev, size_t n, uint64_t counts[5]);
+
+/* Diagnostic: runs the instrumented kernel once over n device-resident rays and returns, per wave of
+ * 64 rays (or per 8x8 tile with the image hint), records[4*w..4*w+3] = {start, end in 100 MHz ticks,
+ * HW_ID register, XCC_ID register}.  capacity is in uint64 elements. */
+int rt_scene_wave_timeline(const rt_scene *s, const void *rays_dev, size_t n, uint64_t *records, size_t capacity);
 
 /* Test hook: runs the kernel's triangle test on n independent (triangle, ray) pairs
  * (host arrays: tri = 3 rt_vec3 per pair) and returns hit flag, t and (u,v) per pair. */

@@ -90,8 +90,10 @@ def _load():
         "ray_scene_intersection": (i32, [vp, sz, vp, vp]),
         "rt_intersect_async": (i32, [vp, vp, sz, vp, vp, vp]),
         "rt_trace_pass": (i32, [vp, vp, vp, vp, sz, C.POINTER(C.c_float), u32, vp]),
-        "rt_scene_count_fetches": (i32, [vp, vp, sz, sz, C.POINTER(u64)]),
+        "rt_scene_count_fetches": (i32, [vp, vp, sz, sz, C.POINTER(u64), vp]),
         "rt_scene_count_fetches_device": (i32, [vp, vp, sz, C.POINTER(u64)]),
+        "rt_scene_wave_timeline": (i32, [vp, vp, sz, vp, sz]),
+        "rt_scene_wave_model": (i32, [vp, vp, sz, u32, u32, sz, i32, C.POINTER(u64)]),
         "rt_debug_tri_batch": (i32, [i32, vp, vp, sz, vp, vp, vp]),
         "rt_write_bmp32": (i32, [C.c_char_p, vp, i32, i32]),
         "rt_write_pfm": (i32, [C.c_char_p, vp, i32, i32]),
@@ -262,11 +264,29 @@ class Scene:
         _check(lib.rt_trace_pass(self._h, _ptr(rays_in_ptr), _ptr(rays_out_ptr), _ptr(rgba_ptr), n, cam_arr, op,
                                  C.c_void_p(stream) if stream else None))
 
-    def count_fetches(self, rays, stride=1):
+    def count_fetches(self, rays, stride=1, per_ray=False):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, RAY_FLOATS)
         v = (C.c_uint64 * 5)()
-        _check(lib.rt_scene_count_fetches(self._h, _ptr(rays), len(rays), stride, v))
-        return dict(zip(["nodes", "tris", "leaves", "rays_hit", "rays"], [int(x) for x in v]))
+        pr = np.zeros(((len(rays) + stride - 1) // stride, 2), np.uint32) if per_ray else None
+        _check(lib.rt_scene_count_fetches(self._h, _ptr(rays), len(rays), stride, v, _ptr(pr)))
+        out = dict(zip(["nodes", "tris", "leaves", "rays_hit", "rays"], [int(x) for x in v]))
+        return (out, pr) if per_ray else out
+
+    def wave_model(self, rays, image_width=0, refill=0, max_waves=0, policy=0):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, RAY_FLOATS)
+        v = (C.c_uint64 * 11)()
+        _check(lib.rt_scene_wave_model(self._h, _ptr(rays), len(rays), image_width, refill, max_waves, policy, v))
+        keys = ["waves", "rays", "wave_node_steps", "lane_node_steps", "wave_tri_steps", "lane_tri_steps",
+                "wave_leaf_phases", "lane_leaf_phases", "refills", "refill_lanes", "max_wave_steps"]
+        return dict(zip(keys, [int(x) for x in v]))
+
+    def wave_timeline(self, rays_ptr, n):
+        """(waves, 4) u64: start tick, end tick (100 MHz), HW_ID, XCC_ID of every wave of one instrumented launch."""
+        cap = ((n + 63) // 64 + 64) * 4 * 2
+        out = np.zeros(cap, np.uint64)
+        _check(lib.rt_scene_wave_timeline(self._h, _ptr(rays_ptr), n, _ptr(out), cap))
+        out = out.reshape(-1, 4)
+        return out[out[:, 1] != 0]
 
     def count_fetches_device(self, rays_ptr, n):
         v = (C.c_uint64 * 5)()
@@ -275,7 +295,7 @@ class Scene:
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:
             lib.rt_scene_destroy(h)
 
     def __del__(self):

@@ -5,7 +5,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -64,6 +66,8 @@ int Upload(T **dst, const void *src, size_t bytes)
 
 constexpr int kCounterSlots = 64;        // ray cursors, one 128-byte line each, used round-robin
 constexpr int kCounterStride = 32;       // uint32 per slot
+constexpr uint32_t kFeedbackMaxRays = 1u << 30;  // single-launch calls only
+constexpr int kStatShards = 64;          // instrumented build: counter shards, 16 uint64 (one line) each
 
 }  // namespace
 
@@ -84,6 +88,15 @@ struct rt_scene {
   int blocks_per_cu = 8;
   int quant = 1;                 // traverse the 16-bit quantized records (16 B per child) instead of float boxes
   int block_threads = 256;       // workgroup size: 64, 128 or 256
+  int centre_first = 1;          // image mode: dispatch tiles nearest the image centre first
+  mutable uint32_t *d_order = nullptr;   // cached dispatch order for (order_w, order_h)
+  mutable uint32_t order_w = 0, order_h = 0;
+  int feedback = 0;              // reuse the previous launch's per-unit cost to start expensive units first
+  mutable uint32_t *d_fb_cost = nullptr, *d_fb_order = nullptr;
+  mutable uint32_t fb_ntasks = 0, fb_n = 0, fb_img_w = 0;  // shape the feedback buffers describe
+  mutable int fb_valid = -1;     // >= 0 once d_fb_cost holds a finished launch's costs
+  int leaf_pct = 50;             // node/leaf step scheduling threshold (percent of busy lanes parked at a leaf)
+  int extra_stack = 0;           // diagnostic: extra LDS stack entries per lane (lowers occupancy)
   int image_width = 0;           // hint: ray arrays are row-major images of this width (0 = unstructured)
   rt::FlatScene flat;          // host copy (fetch counting, info)
   size_t nverts = 0, ntris = 0, nnormals = 0, nmats = 0;
@@ -115,9 +128,45 @@ void FillArgs(const rt_scene *s, rt::KernelArgs &a)
   a.mats = s->d_mats;
   a.nnormals = static_cast<uint32_t>(s->nnormals);
   a.nmats = static_cast<uint32_t>(s->nmats);
-  a.stack_entries = static_cast<uint32_t>(s->width == 4 ? s->flat.stack4 : s->flat.stack2);
+  a.stack_entries = static_cast<uint32_t>((s->width == 4 ? s->flat.stack4 : s->flat.stack2) + s->extra_stack);
   a.scale = s->flat.scale;
+  a.leaf_pct = static_cast<uint32_t>(s->leaf_pct);
   a.stats = s->d_stats;
+}
+
+// Dispatch order for a W x H image walked in 8x8 tiles: 16x16-pixel groups of four tiles (one workgroup's
+// worth) sorted by their distance from the image centre, nearest first.  For a framed object those are the
+// tiles whose rays traverse deepest; starting them first keeps the few long-running waves from being the
+// last ones standing while the rest of the chip idles.  Purely a schedule: every tile is traced exactly once.
+int EnsureOrder(const rt_scene *s, uint32_t w, uint32_t h)
+{
+  if (s->d_order && s->order_w == w && s->order_h == h) return RT_OK;
+  const uint32_t tx = (w + 7u) / 8u, ty = (h + 7u) / 8u, gx = (tx + 1u) / 2u, gy = (ty + 1u) / 2u;
+  std::vector<std::pair<float, uint32_t>> groups;
+  groups.reserve(static_cast<size_t>(gx) * gy);
+  for (uint32_t j = 0; j < gy; ++j)
+    for (uint32_t i = 0; i < gx; ++i) {
+      const float dx = ((i + 0.5f) * 16.f - 0.5f * w) / (0.5f * w), dy = ((j + 0.5f) * 16.f - 0.5f * h) / (0.5f * h);
+      groups.emplace_back(dx * dx + dy * dy, j * gx + i);
+    }
+  std::stable_sort(groups.begin(), groups.end());
+  std::vector<uint32_t> order;
+  order.reserve(static_cast<size_t>(tx) * ty);
+  for (auto const &g : groups) {
+    const uint32_t i = g.second % gx, j = g.second / gx;
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t x = 2 * i + (k & 1u), y = 2 * j + (k >> 1);
+      if (x < tx && y < ty) order.push_back(y * tx + x);
+    }
+  }
+  if (s->d_order) (void)hipFree(s->d_order); (void)hipFree(s->d_fb_cost); (void)hipFree(s->d_fb_order);
+  s->d_order = nullptr;
+  s->order_w = s->order_h = 0;
+  RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_order), order.size() * sizeof(uint32_t)));
+  RT_HIP(hipMemcpy(s->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  s->order_w = w;
+  s->order_h = h;
+  return RT_OK;
 }
 
 // Enqueues one launch over at most 2^30 rays.
@@ -129,6 +178,11 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     a.img_w = static_cast<uint32_t>(s->image_width);
     a.img_h = a.n / a.img_w;
     a.ntasks = ((a.img_w + 7u) / 8u) * ((a.img_h + 7u) / 8u);
+    if (s->centre_first) {
+      int rc = EnsureOrder(s, a.img_w, a.img_h);
+      if (rc != RT_OK) return rc;
+      a.order = s->d_order;
+    }
   }
   const uint32_t block = static_cast<uint32_t>(s->block_threads), wpb = block / 64u;
   const uint32_t blocks_needed = (a.ntasks + wpb - 1u) / wpb;
@@ -141,6 +195,25 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     s->next_counter = (slot + 1) % kCounterSlots;
     a.counter = s->d_counters + slot * kCounterStride;
     RT_HIP(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream));
+  }
+  if (s->feedback && !count && a.n < kFeedbackMaxRays) {
+    if (s->fb_ntasks != a.ntasks || s->fb_n != a.n || s->fb_img_w != a.img_w) {  // new shape: start over
+      (void)hipFree(s->d_fb_cost); (void)hipFree(s->d_fb_order);
+      s->d_fb_cost = s->d_fb_order = nullptr;
+      s->fb_valid = -1;
+      s->fb_ntasks = s->fb_n = s->fb_img_w = 0;
+      const size_t padded = static_cast<size_t>(rt::BuildOrderKeysPerThread(a.ntasks)) * 1024u;
+      RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_cost), padded * sizeof(uint32_t)));
+      RT_HIP(hipMemsetAsync(s->d_fb_cost, 0, padded * sizeof(uint32_t), stream));
+      RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_order), static_cast<size_t>(a.ntasks) * sizeof(uint32_t)));
+      s->fb_ntasks = a.ntasks; s->fb_n = a.n; s->fb_img_w = a.img_w;
+    }
+    if (s->fb_valid >= 0) {  // order this launch by the costs the previous one measured
+      RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost, a.ntasks, s->d_fb_order, stream));
+      a.order = s->d_fb_order;
+    }
+    a.unit_cost = s->d_fb_cost;
+    s->fb_valid = 0;
   }
   if (static_cast<size_t>(a.stack_entries) * 1024u > 160u * 1024u)
     return Fail(RT_ERR_INVALID, "bvh too deep for the LDS traversal stack");
@@ -359,7 +432,7 @@ int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, s
   if (rc == RT_OK) rc = Upload(&s->d_normals, normals, nnormals * sizeof(rt_float4));
   if (rc == RT_OK) rc = Upload(&s->d_mats, materials, nmats * sizeof(rt_material));
   if (rc == RT_OK) rc = Upload(&s->d_counters, nullptr, kCounterSlots * kCounterStride * sizeof(uint32_t));
-  if (rc == RT_OK) rc = Upload(&s->d_stats, nullptr, 8 * sizeof(unsigned long long));
+  if (rc == RT_OK) rc = Upload(&s->d_stats, nullptr, kStatShards * 16 * sizeof(unsigned long long));
   if (rc != RT_OK) {
     std::string keep = g_error;
     rt_scene_destroy(s);
@@ -380,7 +453,7 @@ void rt_scene_destroy(rt_scene *s)
   DeviceGuard guard(s->device);
   (void)hipFree(s->d_nodes2); (void)hipFree(s->d_nodes4); (void)hipFree(s->d_nodesq2); (void)hipFree(s->d_nodesq4); (void)hipFree(s->d_tris);
   (void)hipFree(s->d_verts); (void)hipFree(s->d_faces); (void)hipFree(s->d_normals); (void)hipFree(s->d_mats);
-  (void)hipFree(s->d_counters); (void)hipFree(s->d_stats);
+  (void)hipFree(s->d_counters); (void)hipFree(s->d_stats); (void)hipFree(s->d_order); (void)hipFree(s->d_fb_cost); (void)hipFree(s->d_fb_order);
   (void)hipFree(s->d_stage_in); (void)hipFree(s->d_stage_out);
   delete s;
 }
@@ -405,6 +478,17 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
     s->width = value;
   } else if (k == "persistent") {
     s->persistent = value != 0;
+  } else if (k == "feedback") {
+    s->feedback = value != 0;
+    s->fb_valid = -1;
+  } else if (k == "centre_first") {
+    s->centre_first = value != 0;
+  } else if (k == "leaf_pct") {
+    if (value < 1 || value > 100) return Fail(RT_ERR_INVALID, "leaf_pct must be in 1..100");
+    s->leaf_pct = value;
+  } else if (k == "extra_stack") {
+    if (value < 0 || value > 128) return Fail(RT_ERR_INVALID, "extra_stack out of range");
+    s->extra_stack = value;
   } else if (k == "quantized") {
     s->quant = value != 0;
   } else if (k == "block_threads") {
@@ -413,6 +497,7 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "image_width") {
     if (value < 0) return Fail(RT_ERR_INVALID, "image_width must be >= 0");
     s->image_width = value;
+    s->fb_valid = -1;
   } else if (k == "blocks_per_cu") {
     if (value < 1 || value > 64) return Fail(RT_ERR_INVALID, "blocks_per_cu out of range");
     s->blocks_per_cu = value;
@@ -504,13 +589,24 @@ int rt_trace_pass(const rt_scene *s, const void *rays_in_dev, void *rays_out_dev
 }
 
 int rt_scene_count_fetches(const rt_scene *s, const rt_ray_isect *rays_host, size_t n, size_t stride,
-                           uint64_t counts[5])
+                           uint64_t counts[5], uint32_t *per_ray)
 {
   if (!s || !rays_host || !counts) return Fail(RT_ERR_INVALID, "null argument");
   if (stride == 0) stride = 1;
-  rt::FetchCounts fc = rt::CountFetches(s->flat, s->width, s->quant != 0, rays_host, n, stride);
+  rt::FetchCounts fc = rt::CountFetches(s->flat, s->width, s->quant != 0, rays_host, n, stride, per_ray);
   counts[0] = fc.nodes; counts[1] = fc.tris; counts[2] = fc.leaves; counts[3] = fc.rays_hit;
   counts[4] = (n + stride - 1) / stride;
+  return RT_OK;
+}
+
+int rt_scene_wave_model(const rt_scene *s, const rt_ray_isect *rays_host, size_t n, unsigned image_width, unsigned refill,
+                        size_t max_waves, int policy, uint64_t out[11])
+{
+  if (!s || !rays_host || !out) return Fail(RT_ERR_INVALID, "null argument");
+  if (image_width && n % image_width) return Fail(RT_ERR_INVALID, "ray count is not a multiple of image_width");
+  rt::WaveModel m = rt::SimulateWaves(s->flat, s->width, s->quant != 0, rays_host, n, image_width, refill, max_waves, policy);
+  out[0] = m.waves; out[1] = m.rays; out[2] = m.wave_node_steps; out[3] = m.lane_node_steps; out[4] = m.wave_tri_steps;
+  out[5] = m.lane_tri_steps; out[6] = m.wave_leaf_phases; out[7] = m.lane_leaf_phases; out[8] = m.refills; out[9] = m.refill_lanes; out[10] = m.max_wave_steps;
   return RT_OK;
 }
 
@@ -521,7 +617,7 @@ int rt_scene_count_fetches_device(const rt_scene *s, const void *rays_dev, size_
   if (n == 0 || n > kChunk) return Fail(RT_ERR_INVALID, "ray count out of range for the instrumented kernel");
   DeviceGuard guard(s->device);
   if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
-  RT_HIP(hipMemset(s->d_stats, 0, 8 * sizeof(unsigned long long)));
+  RT_HIP(hipMemset(s->d_stats, 0, kStatShards * 16 * sizeof(unsigned long long)));
   int rc = EnsureStage(&s->d_stage_out, &s->stage_out_bytes, n * sizeof(rt_hit16));
   if (rc != RT_OK) return rc;
   rt::KernelArgs a;
@@ -531,11 +627,45 @@ int rt_scene_count_fetches_device(const rt_scene *s, const void *rays_dev, size_
   a.n = static_cast<uint32_t>(n);
   rc = Enqueue(s, a, rt::kModeIntersect, true, nullptr);
   if (rc != RT_OK) return rc;
-  unsigned long long h[4];
+  unsigned long long h[kStatShards * 16];
   RT_HIP(hipMemcpy(h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 4; ++i) counts[i] = h[i];
+  for (int i = 0; i < 4; ++i) {
+    counts[i] = 0;
+    for (int sh = 0; sh < kStatShards; ++sh) counts[i] += h[sh * 16 + i];
+  }
   counts[4] = n;
   return RT_OK;
+}
+
+int rt_scene_wave_timeline(const rt_scene *s, const void *rays_dev, size_t n, uint64_t *records, size_t capacity)
+{
+  if (!s || !rays_dev || !records) return Fail(RT_ERR_INVALID, "null argument");
+  if (s->device == RT_DEVICE_NONE) return Fail(RT_ERR_DEVICE, "scene was created without a device");
+  if (n == 0 || n > kChunk) return Fail(RT_ERR_INVALID, "ray count out of range for the instrumented kernel");
+  DeviceGuard guard(s->device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  int rc = EnsureStage(&s->d_stage_out, &s->stage_out_bytes, n * sizeof(rt_hit16));
+  if (rc != RT_OK) return rc;
+  rt::KernelArgs a;
+  FillArgs(s, a);
+  a.rays = static_cast<const rt_ray_isect *>(rays_dev);
+  a.hits16 = static_cast<rt_hit16 *>(s->d_stage_out);
+  a.n = static_cast<uint32_t>(n);
+  // task count depends on the image hint; compute it the way Enqueue does
+  size_t ntasks = (n + 63) / 64;
+  if (s->image_width > 0 && n % static_cast<size_t>(s->image_width) == 0)
+    ntasks = ((static_cast<size_t>(s->image_width) + 7) / 8) * ((n / s->image_width + 7) / 8);
+  if (capacity < ntasks * 4) return Fail(RT_ERR_INVALID, "timeline buffer too small");
+  unsigned long long *d_tl = nullptr;
+  RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_tl), ntasks * 4 * sizeof(unsigned long long)));
+  hipError_t e = hipMemset(d_tl, 0, ntasks * 4 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(s->d_stats, 0, kStatShards * 16 * sizeof(unsigned long long));
+  a.timeline = d_tl;
+  if (e == hipSuccess) rc = Enqueue(s, a, rt::kModeIntersect, true, nullptr);
+  if (e == hipSuccess && rc == RT_OK) e = hipMemcpy(records, d_tl, ntasks * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  (void)hipFree(d_tl);
+  if (e != hipSuccess) return FailHip(e, "wave timeline");
+  return rc;
 }
 
 int rt_debug_tri_batch(int device, const rt_vec3 *tri, const rt_ray *ray, size_t n, int32_t *hit, float *t, rt_vec2 *uv)

@@ -13,6 +13,7 @@ namespace rt {
 
 constexpr uint32_t kLeafBitDev = 0x80000000u;
 constexpr int kModeIntersect = 0;  // rays used as given (ray_scene_intersection)
+constexpr int kFbBuckets = 16;     // cost bins of the launch-to-launch feedback schedule
 constexpr int kModeTrace = 1;      // full `trace` step: camera / reflection setup + pixel
 
 struct KernelArgs {
@@ -27,8 +28,13 @@ struct KernelArgs {
   const rt_float4 *normals;
   const rt_material *mats;
   float *rgba;                // nullable, kModeTrace only
+  const uint32_t *order;      // nullable, image mode: tile handled by the k-th wave-sized work item
+  // Cost feedback between consecutive launches of the same shape (nullable): every wave stores the number of
+  // traversal iterations its work unit needed; a small sort kernel turns that into the next launch's order.
+  uint32_t *unit_cost;
   uint32_t *counter;          // persistent-wave ray cursor (zeroed before every launch)
   unsigned long long *stats;  // instrumented build only: nodes, tris, leaves, rays hit
+  unsigned long long *timeline;  // instrumented build only, nullable: per wave {start, end (100 MHz ticks), hw id, xcc id}
   uint32_t n;
   uint32_t ntasks;            // wave-sized work items: ceil(n/64), or the number of 8x8 tiles
   uint32_t nnormals;
@@ -37,6 +43,7 @@ struct KernelArgs {
   uint32_t op;                // kModeTrace: 0 = camera transform, 1 = reflect
   uint32_t img_w;             // > 0: rays are a row-major img_w x img_h image, walked in 8x8 pixel tiles per wave
   uint32_t img_h;
+  uint32_t leaf_pct;          // switch from node steps to leaf steps once this percentage of busy lanes hold a leaf
   float scale;                // max |coordinate| of the scene box (slab padding)
   float cam[16];
   QuantGrid grid;             // quantized layouts only
@@ -44,6 +51,10 @@ struct KernelArgs {
 
 hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool persistent, bool count,
                             uint32_t grid, uint32_t block, hipStream_t stream);
+// order[k] = k-th unit to start, costliest bin first, index order within a bin (one 1024-thread workgroup).
+// unit_cost must hold 1024 * BuildOrderKeysPerThread(nunits) readable entries.
+uint32_t BuildOrderKeysPerThread(uint32_t nunits);
+hipError_t LaunchBuildOrder(const uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream);
 hipError_t LaunchTriBatch(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv,
                           hipStream_t stream);
 

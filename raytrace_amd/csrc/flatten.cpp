@@ -225,7 +225,7 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
 
 // Host mirror of the device traversal (same order, same arithmetic) that only counts.
 FetchCounts CountFetches(FlatScene const &fs, int width, bool quant, rt_ray_isect const *rays, size_t nrays,
-                         size_t stride)
+                         size_t stride, uint32_t *per_ray)
 {
   QuantGrid grid;
   for (int k = 0; k < 3; ++k) { grid.lo[k] = fs.grid_lo[k]; grid.step[k] = fs.grid_step[k]; }
@@ -242,6 +242,7 @@ FetchCounts CountFetches(FlatScene const &fs, int width, bool quant, rt_ray_isec
     uint32_t best = 0xFFFFFFFFu;
     size_t sp = 0;
     uint32_t cur = 0;
+    const uint64_t nodes_before = fc.nodes, tris_before = fc.tris;
     for (;;) {
       if (!(cur & kLeafBit)) {
         fc.nodes++;
@@ -306,8 +307,151 @@ FetchCounts CountFetches(FlatScene const &fs, int width, bool quant, rt_ray_isec
       cur = stack[--sp];
     }
     if (best != 0xFFFFFFFFu) fc.rays_hit++;
+    if (per_ray) {
+      per_ray[2 * (k / stride)] = static_cast<uint32_t>(fc.nodes - nodes_before);
+      per_ray[2 * (k / stride) + 1] = static_cast<uint32_t>(fc.tris - tris_before);
+    }
   }
   return fc;
+}
+
+}  // namespace rt
+
+// ---------------------------------------------------------------------------------------
+// Lockstep model of one wave running the traversal kernel: 64 lanes share a program counter,
+// so a phase lasts as long as its slowest lane.  It reports how many wave-level node steps and
+// triangle steps are issued and how many of their lane slots do useful work -- the quantity the
+// VALU-utilisation counter measures -- for the static 64-rays-per-wave assignment and for waves
+// that refill idle lanes from the ray stream once `refill` or more lanes have finished.
+// A planning aid; it computes no hits that anything consumes.
+namespace rt {
+
+namespace {
+
+struct LaneSim {
+  RayCtx r;
+  RayCtxQ rq;
+  float tbest = kFltMax;
+  uint32_t best = 0xFFFFFFFFu;
+  uint32_t cur = 0xFFFFFFFFu;  // kDone
+  std::vector<uint32_t> stack;
+  bool busy = false;
+};
+
+}  // namespace
+
+WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect const *rays, size_t nrays,
+                        uint32_t img_w, uint32_t refill, size_t max_waves, int policy)
+{
+  WaveModel m;
+  QuantGrid grid;
+  for (int k = 0; k < 3; ++k) { grid.lo[k] = fs.grid_lo[k]; grid.step[k] = fs.grid_step[k]; }
+  const uint32_t kDoneRef = 0xFFFFFFFFu;
+  const uint32_t img_h = img_w ? static_cast<uint32_t>(nrays / img_w) : 0;
+  const uint32_t tiles_x = img_w ? (img_w + 7) / 8 : 0;
+  const size_t ntasks = img_w ? static_cast<size_t>(tiles_x) * ((img_h + 7) / 8) : (nrays + 63) / 64;
+  // ray order seen by the stream: task-major, lane-minor; invalid slots skipped
+  auto ray_of = [&](size_t k) -> long long {
+    const size_t task = k / 64, lane = k % 64;
+    if (!img_w) return k < nrays ? static_cast<long long>(k) : -1;
+    const uint32_t x = static_cast<uint32_t>(task % tiles_x) * 8 + (lane & 7), y = static_cast<uint32_t>(task / tiles_x) * 8 + (lane >> 3);
+    return (x < img_w && y < img_h) ? static_cast<long long>(y) * img_w + x : -1;
+  };
+  const size_t stream_len = ntasks * 64;
+  // waves are sampled evenly over the stream; with refill each simulated wave owns a contiguous span
+  const size_t nwaves = std::min(max_waves ? max_waves : ntasks, ntasks);
+  const size_t span = refill ? 64 * 8 : 64;  // a refilling wave works through 8 tiles' worth of rays
+  std::vector<LaneSim> lanes(64);
+  for (size_t w = 0; w < nwaves; ++w) {
+    size_t pos = (ntasks * w / nwaves) * 64, end = std::min(stream_len, pos + span);
+    for (auto &l : lanes) { l.busy = false; l.cur = kDoneRef; }
+    auto assign = [&](LaneSim &l) -> bool {
+      while (pos < end) {
+        long long ri = ray_of(pos++);
+        if (ri < 0) continue;
+        rt_ray_isect const &ry = rays[ri];
+        SetupRay(l.r, ry.origin.x, ry.origin.y, ry.origin.z, ry.direction.x, ry.direction.y, ry.direction.z, fs.scale);
+        SetupRayQ(l.rq, l.r, grid, fs.scale);
+        l.tbest = kFltMax; l.best = 0xFFFFFFFFu; l.cur = 0; l.stack.clear(); l.busy = true;
+        m.rays++;
+        return true;
+      }
+      return false;
+    };
+    for (auto &l : lanes) assign(l);
+    m.waves++;
+    const uint64_t wave_steps_before = m.wave_node_steps + m.wave_tri_steps;
+    for (;;) {
+      // retire / refill
+      uint32_t idle = 0, active = 0;
+      for (auto &l : lanes) { if (l.cur == kDoneRef) idle++; else active++; }
+      if (refill && idle >= refill && pos < end) {
+        uint32_t got = 0;
+        for (auto &l : lanes) if (l.cur == kDoneRef && assign(l)) got++;
+        if (got) { m.refills++; m.refill_lanes += got; }
+        active += got;
+      }
+      if (active == 0) {
+        m.max_wave_steps = std::max(m.max_wave_steps, m.wave_node_steps + m.wave_tri_steps - wave_steps_before);
+        break;
+      }
+      // node phase: until no lane holds an inner reference
+      uint64_t steps_this_wave_before = m.wave_node_steps + m.wave_tri_steps;
+      (void)steps_this_wave_before;
+      for (int node_iter = 0;; ++node_iter) {
+        if (policy == 1 && node_iter == 1) break;  // if-if: one node step, then the leaf part, every iteration
+        uint32_t n_inner = 0, n_leaf = 0;
+        for (auto &l : lanes) { if (!(l.cur & kLeafBit)) n_inner++; else if (l.cur != kDoneRef) n_leaf++; }
+        if (!n_inner) break;
+        // policy >= 2: leave the node loop once `policy` percent of the busy lanes are parked at a leaf
+        if (policy >= 2 && n_leaf * 100u >= static_cast<uint32_t>(policy) * (n_inner + n_leaf)) break;
+        m.wave_node_steps++;
+        m.lane_node_steps += n_inner;
+        for (auto &l : lanes) {
+          if (l.cur & kLeafBit) continue;
+          uint32_t hit_ref[4]; float hit_t[4]; int nh = 0;
+          const int wd = width == 4 ? 4 : 2;
+          if (quant) {
+            GpuChildQ const *c = (wd == 4 ? fs.nodesq4.data() : fs.nodesq2.data()) + static_cast<size_t>(l.cur) * wd;
+            for (int i = 0; i < wd; ++i) { float te; if (SlabTestQ(l.rq, c[i].x, c[i].y, c[i].z, l.tbest, te)) { hit_ref[nh] = c[i].ref; hit_t[nh++] = te; } }
+          } else if (wd == 4) {
+            GpuNode4 const &n = fs.nodes4[l.cur];
+            for (int i = 0; i < 4; ++i) { float te; if (SlabTest(l.r, n.lox[i], n.loy[i], n.loz[i], n.hix[i], n.hiy[i], n.hiz[i], l.tbest, te)) { hit_ref[nh] = n.child[i]; hit_t[nh++] = te; } }
+          } else {
+            GpuNode2 const &n = fs.nodes2[l.cur];
+            float te;
+            if (SlabTest(l.r, n.lo0[0], n.lo0[1], n.lo0[2], n.hi0[0], n.hi0[1], n.hi0[2], l.tbest, te)) { hit_ref[nh] = n.child[0]; hit_t[nh++] = te; }
+            if (SlabTest(l.r, n.lo1[0], n.lo1[1], n.lo1[2], n.hi1[0], n.hi1[1], n.hi1[2], l.tbest, te)) { hit_ref[nh] = n.child[1]; hit_t[nh++] = te; }
+          }
+          for (int i = 1; i < nh; ++i)
+            for (int j = i; j > 0 && hit_t[j] < hit_t[j - 1]; --j) { std::swap(hit_t[j], hit_t[j - 1]); std::swap(hit_ref[j], hit_ref[j - 1]); }
+          for (int i = nh - 1; i >= 1; --i) l.stack.push_back(hit_ref[i]);
+          if (nh) l.cur = hit_ref[0];
+          else if (l.stack.empty()) l.cur = kDoneRef;
+          else { l.cur = l.stack.back(); l.stack.pop_back(); }
+        }
+      }
+      // leaf phase: the wave loops max(count) times
+      uint32_t maxcnt = 0, nleaf = 0;
+      for (auto &l : lanes) if (l.cur != kDoneRef && (l.cur & kLeafBit)) { maxcnt = std::max(maxcnt, l.cur & 7u); nleaf++; }
+      if (nleaf) { m.wave_leaf_phases++; m.lane_leaf_phases += nleaf; }
+      m.wave_tri_steps += maxcnt;
+      for (auto &l : lanes) {
+        if (l.cur == kDoneRef || !(l.cur & kLeafBit)) continue;
+        const uint32_t first = (l.cur & ~kLeafBit) >> 3, cnt = l.cur & 7u;
+        m.lane_tri_steps += cnt;
+        for (uint32_t j = 0; j < cnt; ++j) {
+          GpuTri const &g = fs.tris[first + j];
+          float t, u, v;
+          if (TriTest(g.ax, g.ay, g.az, g.e1x, g.e1y, g.e1z, g.e2x, g.e2y, g.e2z, l.r, t, u, v) &&
+              (t < l.tbest || (t == l.tbest && g.id < l.best))) { l.tbest = t; l.best = g.id; }
+        }
+        if (l.stack.empty()) l.cur = kDoneRef;
+        else { l.cur = l.stack.back(); l.stack.pop_back(); }
+      }
+    }
+  }
+  return m;
 }
 
 }  // namespace rt

@@ -142,8 +142,21 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
 // Host traversal of the flattened layouts, used ONLY to count records fetched per ray
 // (the algorithmic-bytes figure); it returns counters, never hits.
 struct FetchCounts { uint64_t nodes = 0, tris = 0, leaves = 0, rays_hit = 0, max_stack = 0; };
+// per_ray (optional): per_ray[2*i], per_ray[2*i+1] = node and triangle records fetched by the i-th counted ray.
 FetchCounts CountFetches(FlatScene const &fs, int width, bool quant, rt_ray_isect const *rays, size_t nrays,
-                         size_t stride);
+                         size_t stride, uint32_t *per_ray = nullptr);
+
+// Lockstep wave model (see flatten.cpp): issued wave-level steps vs useful lane slots.
+struct WaveModel {
+  uint64_t waves = 0, rays = 0;
+  uint64_t wave_node_steps = 0, lane_node_steps = 0;
+  uint64_t wave_tri_steps = 0, lane_tri_steps = 0;
+  uint64_t wave_leaf_phases = 0, lane_leaf_phases = 0;
+  uint64_t refills = 0, refill_lanes = 0;
+  uint64_t max_wave_steps = 0;  // node + triangle steps of the longest wave
+};
+WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect const *rays, size_t nrays,
+                        uint32_t img_w, uint32_t refill, size_t max_waves, int policy);
 
 // ---- framebuffer output (cpu_raycast/bmp.c:6-56 byte layout) ---------------
 bool WriteBmp32(const char *path, const uint8_t *bgra, int width, int height);

@@ -188,17 +188,28 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
       if (round) break;
     }
     if (base >= p.ntasks * 64u) break;
+    unsigned long long t_start = 0;
+    if (COUNT && p.timeline) t_start = __builtin_amdgcn_s_memrealtime();
     // Ray owned by this lane.  Linear: 64 consecutive records per wave.  Image: the wave covers an
     // 8x8 pixel tile (the reference launches 8x8 work-groups too, img_main.cpp:457-461), which keeps
     // the 64 rays of a wave on neighbouring paths through the tree.
-    uint32_t idx = base + lane;
+    // Which work unit (8x8 tile, or run of 64 records) this wave takes: the k-th entry of the dispatch order.
+    // The order comes from the previous launch's measured costs (costliest first, so the few long-running
+    // waves start first instead of being the last ones alive) or, failing that, runs from the image centre out.
+    uint32_t unit = base >> 6;
+    if (p.order) {
+      unit = p.order[unit];
+    }
+    uint32_t idx = unit * 64u + lane;
     bool valid = idx < p.n;
     if (p.img_w) {
-      const uint32_t tiles_x = (p.img_w + 7u) >> 3, task = base >> 6;
-      const uint32_t x = (task % tiles_x) * 8u + (lane & 7u), y = (task / tiles_x) * 8u + (lane >> 3);
+      const uint32_t tiles_x = (p.img_w + 7u) >> 3;
+      const uint32_t x = (unit % tiles_x) * 8u + (lane & 7u), y = (unit / tiles_x) * 8u + (lane >> 3);
       valid = x < p.img_w && y < p.img_h;
       idx = y * p.img_w + x;
     }
+    uint32_t wave_cost = 0;
+    uint32_t c_node = 0, c_tri = 0, c_leaf = 0, c_hit = 0;  // instrumented build: this lane's counts
     if (valid) {
       const float4 *rp = reinterpret_cast<const float4 *>(p.rays + idx);
       const float4 in_o = LoadF4(rp), in_d = LoadF4(rp + 1);
@@ -232,28 +243,36 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
       uint32_t sp = 0, cur = live ? 0u : kDone;
       uint32_t nnode = 0, ntri = 0, nleaf = 0;
 
-      while (cur != kDone) {
-        // descend through inner records until this lane holds a leaf (or runs dry)
-        while (!(cur & kLeafBitDev)) {
-          if (COUNT) nnode++;
-          if (QUANT)
-            cur = (WIDTH == 4) ? Step4Q(p, rq, cur, best.t, stk, sp) : Step2Q(p, rq, cur, best.t, stk, sp);
-          else
-            cur = (WIDTH == 4) ? Step4(p, r, cur, best.t, stk, sp) : Step2(p, r, cur, best.t, stk, sp);
-        }
-        if (cur != kDone) {
+      // One wave-uniform decision per iteration: take a node step (lanes holding an inner reference) or a
+      // leaf step (lanes parked at a leaf).  Descending until EVERY lane is parked makes the wave wait for its
+      // slowest lane in every phase; testing leaves as soon as they appear wastes the costlier triangle test
+      // on a few lanes.  Switching to the leaf step once `leaf_pct` percent of the busy lanes are parked sits
+      // between the two and shortens both the average and the longest wave.
+      uint32_t iters = 0;
+      for (;;) {
+        iters++;
+        const bool inner = !(cur & kLeafBitDev);
+        const bool parked = !inner && cur != kDone;
+        const unsigned long long mi = __ballot(inner), ml = __ballot(parked);
+        if ((mi | ml) == 0ull) break;
+        const uint32_t ni = __popcll(mi), nl = __popcll(ml);
+        if (ni != 0u && nl * 100u < p.leaf_pct * (ni + nl)) {
+          if (inner) {
+            if (COUNT) nnode++;
+            if (QUANT)
+              cur = (WIDTH == 4) ? Step4Q(p, rq, cur, best.t, stk, sp) : Step2Q(p, rq, cur, best.t, stk, sp);
+            else
+              cur = (WIDTH == 4) ? Step4(p, r, cur, best.t, stk, sp) : Step2(p, r, cur, best.t, stk, sp);
+          }
+        } else if (parked) {
           if (COUNT) nleaf += (cur & 7u) ? 1u : 0u;
           LeafTest<COUNT>(p, r, cur, best, ntri);
           cur = sp ? stk[--sp * 64u] : kDone;
         }
       }
 
-      if (COUNT) {
-        atomicAdd(p.stats + 0, static_cast<unsigned long long>(nnode));
-        atomicAdd(p.stats + 1, static_cast<unsigned long long>(ntri));
-        atomicAdd(p.stats + 2, static_cast<unsigned long long>(nleaf));
-        atomicAdd(p.stats + 3, static_cast<unsigned long long>(best.id != RT_MISS_ID ? 1u : 0u));
-      }
+      wave_cost = iters;
+      if (COUNT) { c_node += nnode; c_tri += ntri; c_leaf += nleaf; c_hit += best.id != RT_MISS_ID ? 1u : 0u; }
 
       // ---- output record (tracekernel.ck:282-286 miss defaults, :373-399 hit) ----------
       const bool hit = best.id != RT_MISS_ID;
@@ -316,6 +335,113 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
       }
       if (MODE == kModeTrace && p.rgba) reinterpret_cast<float4 *>(p.rgba)[idx] = color;
     }
+    if (p.unit_cost) {
+      const uint32_t cost = __builtin_amdgcn_readfirstlane(wave_cost);   // lane 0 always owns a ray
+      if (lane == 0) p.unit_cost[unit] = cost;
+    }
+    if (COUNT) {
+      // one atomic per counter per wave, so the instrumented launch keeps the real launch's timing shape
+      for (int off = 32; off > 0; off >>= 1) {
+        c_node += __shfl_down(c_node, off); c_tri += __shfl_down(c_tri, off);
+        c_leaf += __shfl_down(c_leaf, off); c_hit += __shfl_down(c_hit, off);
+      }
+      if (lane == 0) {
+        // 64 shards, one 128-byte line each: atomics on one line serialise at a few tens per microsecond
+        unsigned long long *sh = p.stats + ((base >> 6) & 63u) * 16u;
+        atomicAdd(sh + 0, static_cast<unsigned long long>(c_node));
+        atomicAdd(sh + 1, static_cast<unsigned long long>(c_tri));
+        atomicAdd(sh + 2, static_cast<unsigned long long>(c_leaf));
+        atomicAdd(sh + 3, static_cast<unsigned long long>(c_hit));
+      }
+    }
+    if (COUNT && p.timeline) {
+      // diagnostic only: when and where this wave ran (the values feed nothing else)
+      __builtin_amdgcn_s_waitcnt(0);
+      const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+      uint32_t hw_id, xcc_id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+      if (lane == 0) {
+        unsigned long long *rec = p.timeline + static_cast<size_t>(base >> 6) * 4u;
+        rec[0] = t_start; rec[1] = t_end; rec[2] = hw_id; rec[3] = xcc_id;
+      }
+    }
+  }
+}
+
+// Counting sort of work units by cost bin (cost / 16, capped), costliest bin first, ascending unit index inside
+// a bin so neighbouring units stay neighbours.  One workgroup of 1024 threads; thread t owns the contiguous run
+// [t*per, (t+1)*per) and reads it 32 keys at a time as eight independent 16-byte loads, so each pass costs a
+// handful of memory round trips instead of one per key.  unit_cost must be readable up to 1024*per entries.
+__device__ __forceinline__ uint32_t CostBin(uint32_t cost) { return min(cost >> 4, static_cast<uint32_t>(kFbBuckets - 1)); }
+
+__global__ void __launch_bounds__(1024) BuildOrderKernel(const uint32_t *unit_cost, uint32_t n, uint32_t per, uint32_t *order)
+{
+  __shared__ uint32_t table[kFbBuckets * 1024];   // [bin, costliest first][thread]: counts, then next free position
+  __shared__ uint32_t partial[1024];
+  const uint32_t t = threadIdx.x, lo = t * per;
+  const uint4 *keys4 = reinterpret_cast<const uint4 *>(unit_cost + lo);   // per is a multiple of 32
+#pragma unroll
+  for (int b = 0; b < kFbBuckets; ++b) table[b * 1024 + t] = 0;
+  // no barrier needed yet: every thread only touches its own column of the table in this pass
+  for (uint32_t c = 0; c < per; c += 32u) {
+    uint4 k[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = keys4[c / 4u + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t v[4] = {k[j].x, k[j].y, k[j].z, k[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (lo + c + 4u * j + e < n) table[(kFbBuckets - 1 - CostBin(v[e])) * 1024 + t] += 1u;
+    }
+  }
+  __syncthreads();
+  // exclusive scan over the flat table (bin-major, thread-minor), one bin row at a time: a wave-level scan by
+  // lane shuffles plus the 16 wave totals, so every LDS access is either conflict-free or a broadcast
+  {
+    const uint32_t lane = t & 63u, w = t >> 6;
+    uint32_t base = 0;
+    for (int b = 0; b < kFbBuckets; ++b) {
+      const uint32_t v = table[b * 1024 + t];
+      uint32_t x = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if (lane >= static_cast<uint32_t>(off)) x += y;
+      }
+      if (lane == 63u) partial[w] = x;
+      __syncthreads();
+      uint32_t before = 0, total = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 16u; ++k) {
+        const uint32_t wt = partial[k];
+        before += k < w ? wt : 0u;
+        total += wt;
+      }
+      table[b * 1024 + t] = base + before + x - v;
+      base += total;
+      __syncthreads();
+    }
+  }
+  for (uint32_t c = 0; c < per; c += 32u) {
+    uint4 k[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = keys4[c / 4u + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t v[4] = {k[j].x, k[j].y, k[j].z, k[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t i = lo + c + 4u * j + e;
+        if (i < n) {
+          uint32_t *cell = &table[(kFbBuckets - 1 - CostBin(v[e])) * 1024 + t];
+          const uint32_t pos = *cell;
+          *cell = pos + 1u;
+          order[pos] = i;
+        }
+      }
+    }
   }
 }
 
@@ -364,6 +490,15 @@ hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode
                  : LaunchLayout<4, false>(a, mode, persistent, count, grid, block, lds, stream);
   return quant ? LaunchLayout<2, true>(a, mode, persistent, count, grid, block, lds, stream)
                : LaunchLayout<2, false>(a, mode, persistent, count, grid, block, lds, stream);
+}
+
+uint32_t BuildOrderKeysPerThread(uint32_t nunits) { return ((nunits + 1023u) / 1024u + 31u) / 32u * 32u; }
+
+hipError_t LaunchBuildOrder(const uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream)
+{
+  hipLaunchKernelGGL(BuildOrderKernel, dim3(1), dim3(1024), 0, stream, unit_cost, nunits, BuildOrderKeysPerThread(nunits),
+                     order);
+  return hipGetLastError();
 }
 
 hipError_t LaunchTriBatch(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv,
