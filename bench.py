@@ -56,8 +56,6 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="dragon1080", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=int(os.environ.get("RT_WIDTH", "0")), help="2 or 4 (0 = library default)")
-    ap.add_argument("--persistent", type=int, default=-1)
-    ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--rays", type=int, default=16 * 1024 * 1024, help="ray count for --workload ao")
     ap.add_argument("--bvh", default="fixed", choices=["fixed", "reference"])
     ap.add_argument("--out", default="full", choices=["full", "compact"], help="64-byte hit records or 16-byte {id,t,u,v}")
@@ -93,16 +91,12 @@ def main():
     scene = rt.Scene(mesh, bvh, device=local, width=4 if a.width == 4 else 2)
     if a.width in (2, 4):
         scene.set_param("width", a.width)
-    if a.persistent >= 0:
-        scene.set_param("persistent", a.persistent)
     if a.extra_stack > 0:
         scene.set_param("extra_stack", a.extra_stack)
     if a.quant >= 0:
         scene.set_param("quantized", a.quant)
     if a.block > 0:
         scene.set_param("block_threads", a.block)
-    if a.blocks_per_cu > 0:
-        scene.set_param("blocks_per_cu", a.blocks_per_cu)
     if W and a.workload != "tiles4k" and a.image_hint:
         scene.set_param("image_width", W)
     info = scene.info()

@@ -100,18 +100,24 @@ void rt_scene_destroy(rt_scene *s);
  *               bytes per bvh2 node, bytes per bvh4 node, bytes per triangle record}
  * (node sizes are those of the layout currently selected by "quantized") */
 int rt_scene_info(const rt_scene *s, uint64_t info[8]);
-/* Tuning knobs: "width" (2 or 4: which record layout the traversal walks), "persistent"
- * (0/1: waves pull rays from a global cursor vs one ray per launched thread),
- * "quantized" (1: records hold 16-bit grid-quantized boxes, 16 bytes per child; 0: float boxes, 32
- * bytes per child; hits are identical), "block_threads" (64, 128 or 256),
- * "feedback" (1: each launch bins its work units by measured traversal cost and the next launch of the same
- * shape on this scene starts the costliest bins first -- a schedule only, every ray is traced every time;
- * launches of one scene must then be issued on one stream at a time), "centre_first" (image mode: 1 dispatches the tiles nearest the image centre first, 0 in row order),
- * "leaf_pct" (1..100: a wave switches from node steps to leaf steps once this share of its busy lanes holds a
- * leaf; 100 = descend until every lane does), "blocks_per_cu" (resident-workgroup cap of the persistent grid), "image_width" (W > 0 declares
- * that ray arrays whose length is a multiple of W are row-major W-wide images, as the reference's
- * 2-D NDRange is, render_client/img_main.cpp:457-461; each wave then takes an 8x8 pixel tile.
- * Results do not depend on it). */
+/* Tuning knobs (none of them changes a result, only the schedule or the record layout walked):
+ *   "width"          2 or 4: which record layout the traversal walks.
+ *   "quantized"      1: records hold 16-bit grid-quantized boxes, 16 bytes per child; 0: float boxes, 32 bytes
+ *                    per child.
+ *   "image_width"    W > 0 declares that ray arrays whose length is a multiple of W are row-major W-wide images,
+ *                    as the reference's 2-D NDRange is (render_client/img_main.cpp:457-461); each wave then
+ *                    takes an 8x8 pixel tile.  0 = unstructured: each wave takes 64 consecutive records.
+ *   "centre_first"   image mode: 1 dispatches the tiles nearest the image centre first, 0 in row order.
+ *   "feedback"       1: every launch records the traversal cost of each wave-sized work unit; a small sort
+ *                    kernel on a library-owned side stream turns that into a costliest-first dispatch order,
+ *                    which the launch after next of the same shape (ray count, image width) on this scene uses.
+ *                    A schedule only: every ray is traced on every launch.  Any change of shape starts over.
+ *   "leaf_pct"       1..100: a wave switches from node steps to leaf steps once this share of its busy lanes
+ *                    holds a leaf; 100 = descend until every lane does.
+ *   "block_threads"  64, 128 or 256.
+ *   "extra_stack"    diagnostic: extra traversal-stack entries per lane (lowers occupancy).
+ * Calls on one scene must not overlap in time from different host threads (the scene caches launch state);
+ * the launches themselves may go to any streams. */
 int rt_scene_set_param(rt_scene *s, const char *key, int value);
 
 /* ------------------------------------------------------------------ device: the hot path

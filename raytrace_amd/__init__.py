@@ -164,7 +164,7 @@ class Mesh:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:
             lib.rt_mesh_destroy(h)
 
 
@@ -188,7 +188,7 @@ class BVH:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:
             lib.rt_bvh_destroy(h)
 
 
@@ -282,7 +282,7 @@ class Scene:
 
     def wave_timeline(self, rays_ptr, n):
         """(waves, 4) u64: start tick, end tick (100 MHz), HW_ID, XCC_ID of every wave of one instrumented launch."""
-        cap = ((n + 63) // 64 + 64) * 4 * 2
+        cap = ((n + 63) // 64 + 64) * 4 * 4
         out = np.zeros(cap, np.uint64)
         _check(lib.rt_scene_wave_timeline(self._h, _ptr(rays_ptr), n, _ptr(out), cap))
         out = out.reshape(-1, 4)

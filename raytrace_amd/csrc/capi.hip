@@ -64,8 +64,6 @@ int Upload(T **dst, const void *src, size_t bytes)
   return RT_OK;
 }
 
-constexpr int kCounterSlots = 64;        // ray cursors, one 128-byte line each, used round-robin
-constexpr int kCounterStride = 32;       // uint32 per slot
 constexpr uint32_t kFeedbackMaxRays = 1u << 30;  // single-launch calls only
 constexpr int kStatShards = 64;          // instrumented build: counter shards, 16 uint64 (one line) each
 
@@ -84,17 +82,18 @@ struct rt_scene {
   int device = 0;
   int num_cu = 256;
   int width = 2;
-  int persistent = 0;            // measured on dragon 1080p: hardware dispatch beats a single global ray cursor
-  int blocks_per_cu = 8;
   int quant = 1;                 // traverse the 16-bit quantized records (16 B per child) instead of float boxes
   int block_threads = 256;       // workgroup size: 64, 128 or 256
   int centre_first = 1;          // image mode: dispatch tiles nearest the image centre first
   mutable uint32_t *d_order = nullptr;   // cached dispatch order for (order_w, order_h)
   mutable uint32_t order_w = 0, order_h = 0;
   int feedback = 0;              // reuse the previous launch's per-unit cost to start expensive units first
-  mutable uint32_t *d_fb_cost = nullptr, *d_fb_order = nullptr;
+  mutable uint32_t *d_fb_cost[2] = {nullptr, nullptr}, *d_fb_order[2] = {nullptr, nullptr};
   mutable uint32_t fb_ntasks = 0, fb_n = 0, fb_img_w = 0;  // shape the feedback buffers describe
-  mutable int fb_valid = -1;     // >= 0 once d_fb_cost holds a finished launch's costs
+  mutable bool fb_sorted[2] = {false, false};               // d_fb_order[k] holds (or will hold, after ev_sort[k]) an order
+  mutable uint32_t fb_launch = 0;
+  mutable hipStream_t side = nullptr;                       // the order-building kernel runs here, beside the next trace
+  mutable hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_sort[2] = {nullptr, nullptr};
   int leaf_pct = 50;             // node/leaf step scheduling threshold (percent of busy lanes parked at a leaf)
   int extra_stack = 0;           // diagnostic: extra LDS stack entries per lane (lowers occupancy)
   int image_width = 0;           // hint: ray arrays are row-major images of this width (0 = unstructured)
@@ -105,9 +104,7 @@ struct rt_scene {
   rt_face *d_faces = nullptr;
   rt_float4 *d_normals = nullptr;
   rt_material *d_mats = nullptr;
-  uint32_t *d_counters = nullptr;
   unsigned long long *d_stats = nullptr;
-  mutable int next_counter = 0;
   // staging for host-pointer calls
   mutable void *d_stage_in = nullptr, *d_stage_out = nullptr;
   mutable size_t stage_in_bytes = 0, stage_out_bytes = 0;
@@ -159,13 +156,28 @@ int EnsureOrder(const rt_scene *s, uint32_t w, uint32_t h)
       if (x < tx && y < ty) order.push_back(y * tx + x);
     }
   }
-  if (s->d_order) (void)hipFree(s->d_order); (void)hipFree(s->d_fb_cost); (void)hipFree(s->d_fb_order);
+  if (s->d_order) (void)hipFree(s->d_order);
   s->d_order = nullptr;
   s->order_w = s->order_h = 0;
   RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_order), order.size() * sizeof(uint32_t)));
   RT_HIP(hipMemcpy(s->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   s->order_w = w;
   s->order_h = h;
+  return RT_OK;
+}
+
+// Drops every piece of launch-to-launch feedback state (after waiting for a sort that may still be running).
+int ResetFeedback(const rt_scene *s)
+{
+  if (s->side) RT_HIP(hipStreamSynchronize(s->side));
+  for (int k = 0; k < 2; ++k) {
+    if (s->d_fb_cost[k]) (void)hipFree(s->d_fb_cost[k]);
+    if (s->d_fb_order[k]) (void)hipFree(s->d_fb_order[k]);
+    s->d_fb_cost[k] = s->d_fb_order[k] = nullptr;
+    s->fb_sorted[k] = false;
+  }
+  s->fb_launch = 0;
+  s->fb_ntasks = s->fb_n = s->fb_img_w = 0;
   return RT_OK;
 }
 
@@ -185,39 +197,52 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     }
   }
   const uint32_t block = static_cast<uint32_t>(s->block_threads), wpb = block / 64u;
-  const uint32_t blocks_needed = (a.ntasks + wpb - 1u) / wpb;
-  const bool persistent = s->persistent && !count;
-  uint32_t grid = blocks_needed;
-  if (persistent) {
-    const uint32_t cap = static_cast<uint32_t>(s->num_cu) * static_cast<uint32_t>(s->blocks_per_cu) * (4u / wpb);
-    if (grid > cap) grid = cap;
-    const int slot = s->next_counter;
-    s->next_counter = (slot + 1) % kCounterSlots;
-    a.counter = s->d_counters + slot * kCounterStride;
-    RT_HIP(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream));
-  }
-  if (s->feedback && !count && a.n < kFeedbackMaxRays) {
+  const uint32_t grid = (a.ntasks + wpb - 1u) / wpb;   // one wave per work unit
+  int fb_slot = -1;
+  if (s->feedback == 1 && !count && a.n < kFeedbackMaxRays) {
     if (s->fb_ntasks != a.ntasks || s->fb_n != a.n || s->fb_img_w != a.img_w) {  // new shape: start over
-      (void)hipFree(s->d_fb_cost); (void)hipFree(s->d_fb_order);
-      s->d_fb_cost = s->d_fb_order = nullptr;
-      s->fb_valid = -1;
-      s->fb_ntasks = s->fb_n = s->fb_img_w = 0;
-      const size_t padded = static_cast<size_t>(rt::BuildOrderKeysPerThread(a.ntasks)) * 1024u;
-      RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_cost), padded * sizeof(uint32_t)));
-      RT_HIP(hipMemsetAsync(s->d_fb_cost, 0, padded * sizeof(uint32_t), stream));
-      RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_order), static_cast<size_t>(a.ntasks) * sizeof(uint32_t)));
+      int rc = ResetFeedback(s);
+      if (rc != RT_OK) return rc;
+      const size_t padded = static_cast<size_t>(rt::BuildOrderKeysPerThread(a.ntasks)) * 512u;
+      for (int k = 0; k < 2; ++k) {
+        RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_cost[k]), padded * sizeof(uint32_t)));
+        RT_HIP(hipMemset(s->d_fb_cost[k], 0, padded * sizeof(uint32_t)));
+        RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_order[k]), static_cast<size_t>(a.ntasks) * sizeof(uint32_t)));
+      }
+      if (!s->side) {
+        RT_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+          RT_HIP(hipEventCreateWithFlags(&s->ev_main[k], hipEventDisableTiming));
+          RT_HIP(hipEventCreateWithFlags(&s->ev_sort[k], hipEventDisableTiming));
+        }
+      }
       s->fb_ntasks = a.ntasks; s->fb_n = a.n; s->fb_img_w = a.img_w;
     }
-    if (s->fb_valid >= 0) {  // order this launch by the costs the previous one measured
-      RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost, a.ntasks, s->d_fb_order, stream));
-      a.order = s->d_fb_order;
+    // Launch k traces in the order sorted from launch k-2's costs; the sort of launch k-1's costs runs on the
+    // side stream next to this launch and is ready for launch k+1.  Set `fb_slot` alternates between the two.
+    fb_slot = static_cast<int>(s->fb_launch & 1u);
+    if (s->fb_sorted[fb_slot]) {
+      RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[fb_slot], 0));
+      a.order = s->d_fb_order[fb_slot];
     }
-    a.unit_cost = s->d_fb_cost;
-    s->fb_valid = 0;
+    a.unit_cost = s->d_fb_cost[fb_slot];
   }
   if (static_cast<size_t>(a.stack_entries) * 1024u > 160u * 1024u)
     return Fail(RT_ERR_INVALID, "bvh too deep for the LDS traversal stack");
-  RT_HIP(rt::LaunchClosestHit(a, s->width, s->quant != 0, mode, persistent, count, grid, block, stream));
+  {
+    hipError_t e_ = rt::LaunchClosestHit(a, s->width, s->quant != 0, mode, count, grid, block, stream);
+    if (e_ != hipSuccess)
+      return Fail(RT_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(e_) + " (grid " + std::to_string(grid) +
+                                     ", block " + std::to_string(block) + ", stack entries " + std::to_string(a.stack_entries) + ")");
+  }
+  if (fb_slot >= 0) {
+    RT_HIP(hipEventRecord(s->ev_main[fb_slot], stream));
+    RT_HIP(hipStreamWaitEvent(s->side, s->ev_main[fb_slot], 0));
+    RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_order[fb_slot], s->side));
+    RT_HIP(hipEventRecord(s->ev_sort[fb_slot], s->side));
+    s->fb_sorted[fb_slot] = true;
+    s->fb_launch++;
+  }
   return RT_OK;
 }
 
@@ -411,8 +436,6 @@ int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, s
   s->device = device;
   s->width = flags == RT_SCENE_WIDE4 ? 4 : 2;
   s->nverts = nverts; s->ntris = ntris; s->nnormals = nnormals; s->nmats = nmats;
-  if (const char *e = std::getenv("RT_PERSISTENT")) s->persistent = std::atoi(e) != 0;
-  if (const char *e = std::getenv("RT_BLOCKS_PER_CU")) s->blocks_per_cu = std::max(1, std::atoi(e));
 
   if (device == RT_DEVICE_NONE) {  // host-only: layouts and fetch counting, nothing traces
     *out = s;
@@ -431,7 +454,6 @@ int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, s
   if (rc == RT_OK) rc = Upload(&s->d_faces, faces, ntris * sizeof(rt_face));
   if (rc == RT_OK) rc = Upload(&s->d_normals, normals, nnormals * sizeof(rt_float4));
   if (rc == RT_OK) rc = Upload(&s->d_mats, materials, nmats * sizeof(rt_material));
-  if (rc == RT_OK) rc = Upload(&s->d_counters, nullptr, kCounterSlots * kCounterStride * sizeof(uint32_t));
   if (rc == RT_OK) rc = Upload(&s->d_stats, nullptr, kStatShards * 16 * sizeof(unsigned long long));
   if (rc != RT_OK) {
     std::string keep = g_error;
@@ -453,7 +475,11 @@ void rt_scene_destroy(rt_scene *s)
   DeviceGuard guard(s->device);
   (void)hipFree(s->d_nodes2); (void)hipFree(s->d_nodes4); (void)hipFree(s->d_nodesq2); (void)hipFree(s->d_nodesq4); (void)hipFree(s->d_tris);
   (void)hipFree(s->d_verts); (void)hipFree(s->d_faces); (void)hipFree(s->d_normals); (void)hipFree(s->d_mats);
-  (void)hipFree(s->d_counters); (void)hipFree(s->d_stats); (void)hipFree(s->d_order); (void)hipFree(s->d_fb_cost); (void)hipFree(s->d_fb_order);
+  (void)hipFree(s->d_stats); (void)hipFree(s->d_order); (void)ResetFeedback(s);
+  if (s->side) {
+    (void)hipStreamDestroy(s->side);
+    for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(s->ev_main[k]); (void)hipEventDestroy(s->ev_sort[k]); }
+  }
   (void)hipFree(s->d_stage_in); (void)hipFree(s->d_stage_out);
   delete s;
 }
@@ -476,11 +502,14 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   if (k == "width") {
     if (value != 2 && value != 4) return Fail(RT_ERR_INVALID, "width must be 2 or 4");
     s->width = value;
-  } else if (k == "persistent") {
-    s->persistent = value != 0;
   } else if (k == "feedback") {
-    s->feedback = value != 0;
-    s->fb_valid = -1;
+    if (value < 0 || value > 1) return Fail(RT_ERR_INVALID, "feedback must be 0 or 1");
+    s->feedback = value;
+    if (s->device != RT_DEVICE_NONE) {
+      DeviceGuard guard(s->device);
+      int rc = ResetFeedback(s);
+      if (rc != RT_OK) return rc;
+    }
   } else if (k == "centre_first") {
     s->centre_first = value != 0;
   } else if (k == "leaf_pct") {
@@ -497,10 +526,6 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "image_width") {
     if (value < 0) return Fail(RT_ERR_INVALID, "image_width must be >= 0");
     s->image_width = value;
-    s->fb_valid = -1;
-  } else if (k == "blocks_per_cu") {
-    if (value < 1 || value > 64) return Fail(RT_ERR_INVALID, "blocks_per_cu out of range");
-    s->blocks_per_cu = value;
   } else {
     return Fail(RT_ERR_INVALID, "unknown parameter " + k);
   }
@@ -655,6 +680,7 @@ int rt_scene_wave_timeline(const rt_scene *s, const void *rays_dev, size_t n, ui
   size_t ntasks = (n + 63) / 64;
   if (s->image_width > 0 && n % static_cast<size_t>(s->image_width) == 0)
     ntasks = ((static_cast<size_t>(s->image_width) + 7) / 8) * ((n / s->image_width + 7) / 8);
+  ntasks *= 3;  // room for the slots of a multi-pass launch
   if (capacity < ntasks * 4) return Fail(RT_ERR_INVALID, "timeline buffer too small");
   unsigned long long *d_tl = nullptr;
   RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_tl), ntasks * 4 * sizeof(unsigned long long)));

@@ -32,7 +32,6 @@ struct KernelArgs {
   // Cost feedback between consecutive launches of the same shape (nullable): every wave stores the number of
   // traversal iterations its work unit needed; a small sort kernel turns that into the next launch's order.
   uint32_t *unit_cost;
-  uint32_t *counter;          // persistent-wave ray cursor (zeroed before every launch)
   unsigned long long *stats;  // instrumented build only: nodes, tris, leaves, rays hit
   unsigned long long *timeline;  // instrumented build only, nullable: per wave {start, end (100 MHz ticks), hw id, xcc id}
   uint32_t n;
@@ -49,10 +48,10 @@ struct KernelArgs {
   QuantGrid grid;             // quantized layouts only
 };
 
-hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool persistent, bool count,
-                            uint32_t grid, uint32_t block, hipStream_t stream);
-// order[k] = k-th unit to start, costliest bin first, index order within a bin (one 1024-thread workgroup).
-// unit_cost must hold 1024 * BuildOrderKeysPerThread(nunits) readable entries.
+hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool count, uint32_t grid,
+                            uint32_t block, hipStream_t stream);
+// order[k] = k-th unit to start, costliest bin first, index order within a bin (one 512-thread workgroup).
+// unit_cost must hold 512 * BuildOrderKeysPerThread(nunits) readable entries.
 uint32_t BuildOrderKeysPerThread(uint32_t nunits);
 hipError_t LaunchBuildOrder(const uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream);
 hipError_t LaunchTriBatch(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv,

@@ -360,7 +360,7 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
   const size_t stream_len = ntasks * 64;
   // waves are sampled evenly over the stream; with refill each simulated wave owns a contiguous span
   const size_t nwaves = std::min(max_waves ? max_waves : ntasks, ntasks);
-  const size_t span = refill ? 64 * 8 : 64;  // a refilling wave works through 8 tiles' worth of rays
+  const size_t span = (refill && refill < 1000u) ? 64 * 8 : 64;  // a refilling wave works through 8 tiles' worth of rays
   std::vector<LaneSim> lanes(64);
   for (size_t w = 0; w < nwaves; ++w) {
     size_t pos = (ntasks * w / nwaves) * 64, end = std::min(stream_len, pos + span);
@@ -385,11 +385,28 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
       // retire / refill
       uint32_t idle = 0, active = 0;
       for (auto &l : lanes) { if (l.cur == kDoneRef) idle++; else active++; }
-      if (refill && idle >= refill && pos < end) {
+      if (refill && refill < 1000u && idle >= refill && pos < end) {
         uint32_t got = 0;
         for (auto &l : lanes) if (l.cur == kDoneRef && assign(l)) got++;
         if (got) { m.refills++; m.refill_lanes += got; }
         active += got;
+      }
+      // optional model of intra-wave work donation: idle lanes take the bottom stack entry of the busiest lane
+      if (refill >= 1000u && active > 0 && idle >= refill - 1000u) {
+        uint32_t events = 0;
+        for (auto &h : lanes) {
+          if (h.cur != kDoneRef) continue;
+          LaneSim *donor = nullptr;
+          for (auto &d : lanes) if (d.cur != kDoneRef && d.stack.size() >= 2 && (!donor || d.stack.size() > donor->stack.size())) donor = &d;
+          if (!donor) break;
+          h.r = donor->r; h.rq = donor->rq; h.tbest = donor->tbest; h.best = donor->best;
+          h.cur = donor->stack.front();
+          donor->stack.erase(donor->stack.begin());
+          h.stack.clear();
+          events++;
+          active++;
+        }
+        if (events) { m.refills++; m.refill_lanes += events; }
       }
       if (active == 0) {
         m.max_wave_steps = std::max(m.max_wave_steps, m.wave_node_steps + m.wave_tri_steps - wave_steps_before);

@@ -12,8 +12,8 @@
 //     pops never bank-conflict, replaces the parent-link state machine (:291-370);
 //   * leaves are runs of 48-byte pre-gathered triangle records instead of index ->
 //     3 x vertex gathers (:159-162);
-//   * waves are persistent and pull 64 rays at a time from a global counter with one
-//     atomic per wave, so a slow tile does not idle the rest of its workgroup's slot;
+//   * every wave owns one work unit (an 8x8 pixel tile, or 64 consecutive records) picked through a
+//     dispatch-order table, so the order in which units start can follow their measured cost;
 //   * reciprocal directions are computed once per ray, not once per box (:73);
 //   * the closest hit is order-independent: on equal t the lower triangle index wins,
 //     which is what an index-order brute-force loop with a strict `<` returns
@@ -170,36 +170,26 @@ __device__ __forceinline__ uint32_t Step4Q(const KernelArgs &p, const RayCtxQ &q
 
 __device__ __forceinline__ float Dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-template <int WIDTH, bool QUANT, int MODE, bool PERSISTENT, bool COUNT>
+template <int WIDTH, bool QUANT, int MODE, bool COUNT>
 __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
 {
   extern __shared__ uint32_t lds_stack[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t *stk = lds_stack + wave * p.stack_entries * 64u + lane;
 
-  for (uint32_t round = 0;; ++round) {
-    uint32_t base;
-    if (PERSISTENT) {
-      uint32_t got = 0;
-      if (lane == 0) got = atomicAdd(p.counter, 64u);
-      base = __builtin_amdgcn_readfirstlane(got);
-    } else {
-      base = (blockIdx.x * (blockDim.x >> 6) + wave) * 64u;
-      if (round) break;
-    }
-    if (base >= p.ntasks * 64u) break;
+  {
+    const uint32_t base = (blockIdx.x * (blockDim.x >> 6) + wave) * 64u;
+    if (base >= p.ntasks * 64u) return;
     unsigned long long t_start = 0;
     if (COUNT && p.timeline) t_start = __builtin_amdgcn_s_memrealtime();
-    // Ray owned by this lane.  Linear: 64 consecutive records per wave.  Image: the wave covers an
-    // 8x8 pixel tile (the reference launches 8x8 work-groups too, img_main.cpp:457-461), which keeps
-    // the 64 rays of a wave on neighbouring paths through the tree.
-    // Which work unit (8x8 tile, or run of 64 records) this wave takes: the k-th entry of the dispatch order.
-    // The order comes from the previous launch's measured costs (costliest first, so the few long-running
-    // waves start first instead of being the last ones alive) or, failing that, runs from the image centre out.
+    // Which work unit this wave takes: the k-th entry of the dispatch order.  The order comes from an earlier
+    // launch's measured costs (costliest first, so the few long-running waves start first instead of being the
+    // last ones alive) or, failing that, runs from the image centre out.
+    // Ray owned by this lane.  Linear: the unit is 64 consecutive records.  Image: the unit is an 8x8 pixel
+    // tile (the reference launches 8x8 work-groups too, img_main.cpp:457-461), which keeps the 64 rays of a
+    // wave on neighbouring paths through the tree.
     uint32_t unit = base >> 6;
-    if (p.order) {
-      unit = p.order[unit];
-    }
+    if (p.order) unit = p.order[unit];
     uint32_t idx = unit * 64u + lane;
     bool valid = idx < p.n;
     if (p.img_w) {
@@ -370,19 +360,19 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
 }
 
 // Counting sort of work units by cost bin (cost / 16, capped), costliest bin first, ascending unit index inside
-// a bin so neighbouring units stay neighbours.  One workgroup of 1024 threads; thread t owns the contiguous run
+// a bin so neighbouring units stay neighbours.  One workgroup of 512 threads; thread t owns the contiguous run
 // [t*per, (t+1)*per) and reads it 32 keys at a time as eight independent 16-byte loads, so each pass costs a
-// handful of memory round trips instead of one per key.  unit_cost must be readable up to 1024*per entries.
+// handful of memory round trips instead of one per key.  unit_cost must be readable up to 512*per entries.
 __device__ __forceinline__ uint32_t CostBin(uint32_t cost) { return min(cost >> 4, static_cast<uint32_t>(kFbBuckets - 1)); }
 
-__global__ void __launch_bounds__(1024) BuildOrderKernel(const uint32_t *unit_cost, uint32_t n, uint32_t per, uint32_t *order)
+__global__ void __launch_bounds__(512) BuildOrderKernel(const uint32_t *unit_cost, uint32_t n, uint32_t per, uint32_t *order)
 {
-  __shared__ uint32_t table[kFbBuckets * 1024];   // [bin, costliest first][thread]: counts, then next free position
-  __shared__ uint32_t partial[1024];
+  __shared__ uint32_t table[kFbBuckets * 512];   // [bin, costliest first][thread]: counts, then next free position
+  __shared__ uint32_t partial[8];
   const uint32_t t = threadIdx.x, lo = t * per;
   const uint4 *keys4 = reinterpret_cast<const uint4 *>(unit_cost + lo);   // per is a multiple of 32
 #pragma unroll
-  for (int b = 0; b < kFbBuckets; ++b) table[b * 1024 + t] = 0;
+  for (int b = 0; b < kFbBuckets; ++b) table[b * 512 + t] = 0;
   // no barrier needed yet: every thread only touches its own column of the table in this pass
   for (uint32_t c = 0; c < per; c += 32u) {
     uint4 k[8];
@@ -393,17 +383,17 @@ __global__ void __launch_bounds__(1024) BuildOrderKernel(const uint32_t *unit_co
       const uint32_t v[4] = {k[j].x, k[j].y, k[j].z, k[j].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (lo + c + 4u * j + e < n) table[(kFbBuckets - 1 - CostBin(v[e])) * 1024 + t] += 1u;
+        if (lo + c + 4u * j + e < n) table[(kFbBuckets - 1 - CostBin(v[e])) * 512 + t] += 1u;
     }
   }
   __syncthreads();
   // exclusive scan over the flat table (bin-major, thread-minor), one bin row at a time: a wave-level scan by
-  // lane shuffles plus the 16 wave totals, so every LDS access is either conflict-free or a broadcast
+  // lane shuffles plus the 8 wave totals, so every LDS access is either conflict-free or a broadcast
   {
     const uint32_t lane = t & 63u, w = t >> 6;
     uint32_t base = 0;
     for (int b = 0; b < kFbBuckets; ++b) {
-      const uint32_t v = table[b * 1024 + t];
+      const uint32_t v = table[b * 512 + t];
       uint32_t x = v;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
@@ -414,12 +404,12 @@ __global__ void __launch_bounds__(1024) BuildOrderKernel(const uint32_t *unit_co
       __syncthreads();
       uint32_t before = 0, total = 0;
 #pragma unroll
-      for (uint32_t k = 0; k < 16u; ++k) {
+      for (uint32_t k = 0; k < 8u; ++k) {
         const uint32_t wt = partial[k];
         before += k < w ? wt : 0u;
         total += wt;
       }
-      table[b * 1024 + t] = base + before + x - v;
+      table[b * 512 + t] = base + before + x - v;
       base += total;
       __syncthreads();
     }
@@ -435,7 +425,7 @@ __global__ void __launch_bounds__(1024) BuildOrderKernel(const uint32_t *unit_co
       for (int e = 0; e < 4; ++e) {
         const uint32_t i = lo + c + 4u * j + e;
         if (i < n) {
-          uint32_t *cell = &table[(kFbBuckets - 1 - CostBin(v[e])) * 1024 + t];
+          uint32_t *cell = &table[(kFbBuckets - 1 - CostBin(v[e])) * 512 + t];
           const uint32_t pos = *cell;
           *cell = pos + 1u;
           order[pos] = i;
@@ -460,43 +450,42 @@ __global__ void TriBatchKernel(const rt_vec3 *tri, const rt_ray *ray, uint32_t n
   uv[i].v = v;
 }
 
-template <int WIDTH, bool QUANT, int MODE, bool PERSISTENT, bool COUNT>
+template <int WIDTH, bool QUANT, int MODE, bool COUNT>
 hipError_t LaunchOne(const KernelArgs &a, uint32_t grid, uint32_t block, size_t lds, hipStream_t stream)
 {
-  hipLaunchKernelGGL((ClosestHitKernel<WIDTH, QUANT, MODE, PERSISTENT, COUNT>), dim3(grid), dim3(block), lds, stream, a);
+  (void)hipGetLastError();  // the launch status below must be this launch's, not an earlier call's leftover
+  hipLaunchKernelGGL((ClosestHitKernel<WIDTH, QUANT, MODE, COUNT>), dim3(grid), dim3(block), lds, stream, a);
   return hipGetLastError();
 }
 
 template <int WIDTH, bool QUANT>
-hipError_t LaunchLayout(const KernelArgs &a, int mode, bool persistent, bool count, uint32_t grid, uint32_t block,
-                        size_t lds, hipStream_t stream)
+hipError_t LaunchLayout(const KernelArgs &a, int mode, bool count, uint32_t grid, uint32_t block, size_t lds,
+                        hipStream_t stream)
 {
-  if (count) return LaunchOne<WIDTH, QUANT, kModeIntersect, false, true>(a, grid, block, lds, stream);
-  if (mode == kModeTrace)
-    return persistent ? LaunchOne<WIDTH, QUANT, kModeTrace, true, false>(a, grid, block, lds, stream)
-                      : LaunchOne<WIDTH, QUANT, kModeTrace, false, false>(a, grid, block, lds, stream);
-  return persistent ? LaunchOne<WIDTH, QUANT, kModeIntersect, true, false>(a, grid, block, lds, stream)
-                    : LaunchOne<WIDTH, QUANT, kModeIntersect, false, false>(a, grid, block, lds, stream);
+  if (count) return LaunchOne<WIDTH, QUANT, kModeIntersect, true>(a, grid, block, lds, stream);
+  if (mode == kModeTrace) return LaunchOne<WIDTH, QUANT, kModeTrace, false>(a, grid, block, lds, stream);
+  return LaunchOne<WIDTH, QUANT, kModeIntersect, false>(a, grid, block, lds, stream);
 }
 
 }  // namespace
 
-hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool persistent, bool count,
-                            uint32_t grid, uint32_t block, hipStream_t stream)
+hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool count, uint32_t grid,
+                            uint32_t block, hipStream_t stream)
 {
   const size_t lds = static_cast<size_t>(a.stack_entries) * 4u * block;  // entries x 4 B x lanes of the workgroup
   if (width == 4)
-    return quant ? LaunchLayout<4, true>(a, mode, persistent, count, grid, block, lds, stream)
-                 : LaunchLayout<4, false>(a, mode, persistent, count, grid, block, lds, stream);
-  return quant ? LaunchLayout<2, true>(a, mode, persistent, count, grid, block, lds, stream)
-               : LaunchLayout<2, false>(a, mode, persistent, count, grid, block, lds, stream);
+    return quant ? LaunchLayout<4, true>(a, mode, count, grid, block, lds, stream)
+                 : LaunchLayout<4, false>(a, mode, count, grid, block, lds, stream);
+  return quant ? LaunchLayout<2, true>(a, mode, count, grid, block, lds, stream)
+               : LaunchLayout<2, false>(a, mode, count, grid, block, lds, stream);
 }
 
-uint32_t BuildOrderKeysPerThread(uint32_t nunits) { return ((nunits + 1023u) / 1024u + 31u) / 32u * 32u; }
+uint32_t BuildOrderKeysPerThread(uint32_t nunits) { return ((nunits + 511u) / 512u + 31u) / 32u * 32u; }
 
 hipError_t LaunchBuildOrder(const uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream)
 {
-  hipLaunchKernelGGL(BuildOrderKernel, dim3(1), dim3(1024), 0, stream, unit_cost, nunits, BuildOrderKeysPerThread(nunits),
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(BuildOrderKernel, dim3(1), dim3(512), 0, stream, unit_cost, nunits, BuildOrderKeysPerThread(nunits),
                      order);
   return hipGetLastError();
 }

@@ -36,7 +36,7 @@ def compare(rt, oracle, mesh, rays, hits, sel=None):
 
 
 @pytest.mark.parametrize("width", [2, 4])
-@pytest.mark.parametrize("persistent,quant", [(0, 1), (1, 1), (0, 0)])
+@pytest.mark.parametrize("quant", [1, 0])
 @pytest.mark.parametrize("model,loader,W,H,stride", [
     ("cube.obj", "tolerant", 512, 512, 1),             # exact ties on the shared face diagonals
     ("cube_mirror_test.obj", "reference", 200, 120, 1),
@@ -44,11 +44,10 @@ def compare(rt, oracle, mesh, rays, hits, sel=None):
     ("bunny.obj", "tolerant", 1920, 1080, 257),
     ("dragon.obj", "tolerant", 1920, 1080, 257),
 ])
-def test_primary_rays_match_oracle(rt, oracle, gpu, model, loader, W, H, stride, width, persistent, quant):
+def test_primary_rays_match_oracle(rt, oracle, gpu, model, loader, W, H, stride, width, quant):
     mesh = rt.Mesh.load_obj(os.path.join(MODELS, model), loader)
     bvh = rt.BVH(mesh, "fixed")
     scene = rt.Scene(mesh, bvh, device=gpu, width=width)
-    scene.set_param("persistent", persistent)
     scene.set_param("quantized", quant)
     if W % 8 == 0:
         scene.set_param("image_width", W)
@@ -121,8 +120,8 @@ def test_incoherent_rays_match_oracle(rt, oracle, gpu):
 
 
 def test_full_size_properties(rt, gpu):
-    """BASELINE sizes, checked through size-independent properties: the two record layouts and both
-    launch modes agree on every one of the 2 073 600 / 8 294 400 rays, hit records are
+    """BASELINE sizes, checked through size-independent properties: the record layouts and both
+    ray-to-lane mappings agree on every one of the 2 073 600 / 8 294 400 rays, hit records are
     self-consistent (origin + t*dir lands on the reported hit point, barycentrics inside the
     triangle), and tracing the hit set again is idempotent."""
     mesh = rt.Mesh.load_obj(os.path.join(MODELS, "dragon.obj"), "tolerant")
@@ -130,9 +129,8 @@ def test_full_size_properties(rt, gpu):
     for (W, H) in ((1920, 1080), (3840, 2160)):
         rays = framed_primary(rt, bvh, W, H)
         ref = None
-        for width, persistent, quant, hint in ((2, 0, 1, 0), (4, 0, 1, W), (2, 1, 1, W), (2, 0, 0, W), (4, 0, 0, 0)):
+        for width, quant, hint in ((2, 1, 0), (4, 1, W), (2, 0, W), (4, 0, 0)):
             s = rt.Scene(mesh, bvh, device=gpu, width=width)
-            s.set_param("persistent", persistent)
             s.set_param("quantized", quant)
             s.set_param("image_width", hint)
             hits = s.intersect(rays)
@@ -280,3 +278,45 @@ def test_fetch_counters_agree_between_host_and_device(rt, gpu):
             host = scene.count_fetches(rays)
             assert dev == host, (quant, dev, host)
         scene.close()
+
+
+def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
+    """Dispatch order, cost feedback between launches, step scheduling threshold and workgroup size only
+    decide WHEN a ray is traced.  Every setting, and every repeat of a launch (the feedback order changes
+    from launch to launch), must return the same bits; one of them is checked against the oracle."""
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny.obj"), "tolerant")
+    bvh = rt.BVH(mesh, "fixed")
+    W, H = 640, 360
+    rays = framed_primary(rt, bvh, W, H)
+    scene = rt.Scene(mesh, bvh, device=gpu, width=2)
+    base = scene.intersect(rays)
+    compare(rt, oracle, mesh, rays, base, np.arange(0, len(rays), 61))
+    settings = [
+        dict(image_width=W, centre_first=0),
+        dict(image_width=W, centre_first=1),
+        dict(image_width=W, feedback=1),
+        dict(image_width=0, feedback=1),
+        dict(image_width=W, feedback=1, block_threads=64),
+        dict(image_width=W, feedback=1, block_threads=128),
+        dict(image_width=W, leaf_pct=1),
+        dict(image_width=W, leaf_pct=100),
+        dict(image_width=W, leaf_pct=37, block_threads=128, width=4),
+        dict(image_width=W, quantized=0, feedback=1, width=4),
+    ]
+    defaults = dict(width=2, quantized=1, block_threads=256, image_width=0, leaf_pct=50,
+                    centre_first=1, feedback=0)
+    for cfg in settings:
+        for k, v in {**defaults, **cfg}.items():
+            scene.set_param(k, v)
+        for rep in range(4):      # launches 2 and 3 run in an order sorted from launches 0 and 1
+            out = scene.intersect(rays)
+            assert np.array_equal(bits(out), bits(base)), (cfg, rep)
+    # feedback state survives a change of shape and of rays between launches
+    scene.set_param("feedback", 1)
+    scene.set_param("image_width", W)
+    for n in (len(rays), W * 8, len(rays), 1000, len(rays)):
+        for rep in range(3):
+            shifted = np.roll(rays[:n], rep * 17, axis=0)
+            out = scene.intersect(shifted)
+            assert np.array_equal(bits(out), bits(np.roll(base[:n], rep * 17, axis=0))), (n, rep)
+    scene.close()

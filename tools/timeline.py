@@ -17,8 +17,10 @@ for kv in cfg.split(","):
         scene.set_param(k, W if v == "W" else int(v))
 rays = rt.primary_rays(W, H, rt.frame_camera(bvh.root_box, W, H))
 d = torch.from_numpy(rays).cuda()
-for _ in range(2):
+for _ in range(4):
     tl = scene.wave_timeline(d.data_ptr(), len(rays))
+long = (tl[:, 1] - tl[:, 0]) > 100  # > 1 us: waves that actually traced
+print('slots', len(tl), 'of which traced', int(long.sum()))
 t0 = tl[:, 0].min()
 start = (tl[:, 0] - t0).astype(np.float64) / 100.0   # us
 end = (tl[:, 1] - t0).astype(np.float64) / 100.0
