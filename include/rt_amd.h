@@ -112,9 +112,6 @@ int rt_scene_info(const rt_scene *s, uint64_t info[8]);
  *                    kernel on a library-owned side stream turns that into a costliest-first dispatch order,
  *                    which the launch after next of the same shape (ray count, image width) on this scene uses.
  *                    A schedule only: every ray is traced on every launch.  Any change of shape starts over.
- *   "split_pct"      0..300 (with "feedback"): that many percent more waves than work units are launched and
- *                    the sort gives the spare ones to the costliest units, whose rays are then traced by two
- *                    or four waves (a half or a quarter of the unit each) instead of one.
  *   "leaf_pct"       1..100: a wave switches from node steps to leaf steps once this share of its busy lanes
  *                    holds a leaf; 100 = descend until every lane does.
  *   "block_threads"  64, 128 or 256.

@@ -94,7 +94,6 @@ struct rt_scene {
   mutable uint32_t fb_launch = 0;
   mutable hipStream_t side = nullptr;                       // the order-building kernel runs here, beside the next trace
   mutable hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_sort[2] = {nullptr, nullptr};
-  int split_pct = 12;            // feedback: spare wave slots (percent of units) for splitting the costliest units
   int leaf_pct = 50;             // node/leaf step scheduling threshold (percent of busy lanes parked at a leaf)
   int extra_stack = 0;           // diagnostic: extra LDS stack entries per lane (lowers occupancy)
   int image_width = 0;           // hint: ray arrays are row-major images of this width (0 = unstructured)
@@ -167,13 +166,6 @@ int EnsureOrder(const rt_scene *s, uint32_t w, uint32_t h)
   return RT_OK;
 }
 
-// Wave slots of a launch that follows a cost-sorted order: one per unit plus `split_pct` percent spare ones,
-// which the sort hands to the costliest units as extra parts.
-uint32_t FeedbackSlots(const rt_scene *s, uint32_t ntasks)
-{
-  return ntasks + static_cast<uint32_t>(static_cast<uint64_t>(ntasks) * static_cast<uint32_t>(s->split_pct) / 100u);
-}
-
 // Drops every piece of launch-to-launch feedback state (after waiting for a sort that may still be running).
 int ResetFeedback(const rt_scene *s)
 {
@@ -205,7 +197,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     }
   }
   const uint32_t block = static_cast<uint32_t>(s->block_threads), wpb = block / 64u;
-  a.nslots = a.ntasks;   // one wave per work unit unless a cost-sorted order says otherwise
+  const uint32_t grid = (a.ntasks + wpb - 1u) / wpb;   // one wave per work unit
   int fb_slot = -1;
   if (s->feedback == 1 && !count && a.n < kFeedbackMaxRays) {
     if (s->fb_ntasks != a.ntasks || s->fb_n != a.n || s->fb_img_w != a.img_w) {  // new shape: start over
@@ -215,7 +207,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
       for (int k = 0; k < 2; ++k) {
         RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_cost[k]), padded * sizeof(uint32_t)));
         RT_HIP(hipMemset(s->d_fb_cost[k], 0, padded * sizeof(uint32_t)));
-        RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_order[k]), static_cast<size_t>(FeedbackSlots(s, a.ntasks)) * sizeof(uint32_t)));
+        RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_order[k]), static_cast<size_t>(a.ntasks) * sizeof(uint32_t)));
       }
       if (!s->side) {
         RT_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
@@ -232,11 +224,9 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     if (s->fb_sorted[fb_slot]) {
       RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[fb_slot], 0));
       a.order = s->d_fb_order[fb_slot];
-      a.nslots = FeedbackSlots(s, a.ntasks);
     }
     a.unit_cost = s->d_fb_cost[fb_slot];
   }
-  const uint32_t grid = (a.nslots + wpb - 1u) / wpb;
   if (static_cast<size_t>(a.stack_entries) * 1024u > 160u * 1024u)
     return Fail(RT_ERR_INVALID, "bvh too deep for the LDS traversal stack");
   {
@@ -248,7 +238,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
   if (fb_slot >= 0) {
     RT_HIP(hipEventRecord(s->ev_main[fb_slot], stream));
     RT_HIP(hipStreamWaitEvent(s->side, s->ev_main[fb_slot], 0));
-    RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_order[fb_slot], FeedbackSlots(s, a.ntasks), s->side));
+    RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_order[fb_slot], s->side));
     RT_HIP(hipEventRecord(s->ev_sort[fb_slot], s->side));
     s->fb_sorted[fb_slot] = true;
     s->fb_launch++;
@@ -515,14 +505,6 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "feedback") {
     if (value < 0 || value > 1) return Fail(RT_ERR_INVALID, "feedback must be 0 or 1");
     s->feedback = value;
-    if (s->device != RT_DEVICE_NONE) {
-      DeviceGuard guard(s->device);
-      int rc = ResetFeedback(s);
-      if (rc != RT_OK) return rc;
-    }
-  } else if (k == "split_pct") {
-    if (value < 0 || value > 300) return Fail(RT_ERR_INVALID, "split_pct must be in 0..300");
-    s->split_pct = value;
     if (s->device != RT_DEVICE_NONE) {
       DeviceGuard guard(s->device);
       int rc = ResetFeedback(s);

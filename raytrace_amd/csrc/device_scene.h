@@ -15,10 +15,6 @@ constexpr uint32_t kLeafBitDev = 0x80000000u;
 constexpr int kModeIntersect = 0;  // rays used as given (ray_scene_intersection)
 constexpr int kFbBuckets = 16;     // cost bins of the launch-to-launch feedback schedule
 constexpr int kModeTrace = 1;      // full `trace` step: camera / reflection setup + pixel
-// Dispatch-order entry: work unit, which part of it this wave traces, log2 of the number of parts (0, 1 or 2).
-constexpr uint32_t kEntryUnitMask = 0x03FFFFFFu;
-constexpr uint32_t kEntryPartShift = 26, kEntryLogShift = 28;
-constexpr uint32_t kNoWork = 0xFFFFFFFFu;   // slot left empty
 
 struct KernelArgs {
   const float4 *nodes;        // float boxes: 4 (two-wide) or 8 (four-wide) float4 per record;
@@ -32,15 +28,14 @@ struct KernelArgs {
   const rt_float4 *normals;
   const rt_material *mats;
   float *rgba;                // nullable, kModeTrace only
-  const uint32_t *order;      // nullable: dispatch-order entry of every wave slot
-  // Cost feedback between launches of the same shape (nullable): every wave adds the number of traversal
-  // iterations it needed to its work unit's entry; a small sort kernel turns that into a later launch's order.
+  const uint32_t *order;      // nullable, image mode: tile handled by the k-th wave-sized work item
+  // Cost feedback between consecutive launches of the same shape (nullable): every wave stores the number of
+  // traversal iterations its work unit needed; a small sort kernel turns that into the next launch's order.
   uint32_t *unit_cost;
   unsigned long long *stats;  // instrumented build only: nodes, tris, leaves, rays hit
   unsigned long long *timeline;  // instrumented build only, nullable: per wave {start, end (100 MHz ticks), hw id, xcc id}
   uint32_t n;
-  uint32_t ntasks;            // wave-sized work units: ceil(n/64), or the number of 8x8 tiles
-  uint32_t nslots;            // waves launched: ntasks, or more when the order splits heavy units
+  uint32_t ntasks;            // wave-sized work items: ceil(n/64), or the number of 8x8 tiles
   uint32_t nnormals;
   uint32_t nmats;
   uint32_t stack_entries;     // LDS stack entries per lane
@@ -55,11 +50,10 @@ struct KernelArgs {
 
 hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool count, uint32_t grid,
                             uint32_t block, hipStream_t stream);
-// order[k] = entry of wave slot k, costliest bin first, index order within a bin (one 512-thread workgroup);
-// nslots >= nunits entries are written, the spare ones going to extra parts of the costliest units.
-// unit_cost must hold 512 * BuildOrderKeysPerThread(nunits) entries and is zeroed after being read.
+// order[k] = k-th unit to start, costliest bin first, index order within a bin (one 512-thread workgroup).
+// unit_cost must hold 512 * BuildOrderKeysPerThread(nunits) readable entries.
 uint32_t BuildOrderKeysPerThread(uint32_t nunits);
-hipError_t LaunchBuildOrder(uint32_t *unit_cost, uint32_t nunits, uint32_t *order, uint32_t nslots, hipStream_t stream);
+hipError_t LaunchBuildOrder(const uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream);
 hipError_t LaunchTriBatch(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv,
                           hipStream_t stream);
 

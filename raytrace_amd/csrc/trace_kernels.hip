@@ -178,38 +178,26 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
   uint32_t *stk = lds_stack + wave * p.stack_entries * 64u + lane;
 
   {
-    const uint32_t base = (blockIdx.x * (blockDim.x >> 6) + wave) * 64u;   // 64 x this wave's slot
-    if (base >= p.nslots * 64u) return;
+    const uint32_t base = (blockIdx.x * (blockDim.x >> 6) + wave) * 64u;
+    if (base >= p.ntasks * 64u) return;
     unsigned long long t_start = 0;
     if (COUNT && p.timeline) t_start = __builtin_amdgcn_s_memrealtime();
-    // Which work unit this wave takes: the entry of the dispatch order at its slot.  The order comes from an
-    // earlier launch's measured costs (costliest first, so the few long-running waves start first instead of
-    // being the last ones alive) or, failing that, runs from the image centre out.  A cost-sorted order may give
-    // a heavy unit to two or four waves, each tracing a half or a quarter of its rays: a wave's run time is the
-    // length of its chain of dependent steps, which follows the UNION of its lanes' paths, and those few chains
-    // are what the whole launch ends up waiting for.
-    uint32_t unit = base >> 6, part = 0, parts_log2 = 0;
-    if (p.order) {
-      const uint32_t entry = p.order[unit];
-      if (entry == kNoWork) return;
-      unit = entry & kEntryUnitMask;
-      part = (entry >> kEntryPartShift) & 3u;
-      parts_log2 = entry >> kEntryLogShift;
-    }
+    // Which work unit this wave takes: the k-th entry of the dispatch order.  The order comes from an earlier
+    // launch's measured costs (costliest first, so the few long-running waves start first instead of being the
+    // last ones alive) or, failing that, runs from the image centre out.
     // Ray owned by this lane.  Linear: the unit is 64 consecutive records.  Image: the unit is an 8x8 pixel
     // tile (the reference launches 8x8 work-groups too, img_main.cpp:457-461), which keeps the 64 rays of a
     // wave on neighbouring paths through the tree.
+    uint32_t unit = base >> 6;
+    if (p.order) unit = p.order[unit];
     uint32_t idx = unit * 64u + lane;
     bool valid = idx < p.n;
-    uint32_t lane_part = lane >> (6u - parts_log2);          // runs of 32 or 16 records
     if (p.img_w) {
       const uint32_t tiles_x = (p.img_w + 7u) >> 3;
       const uint32_t x = (unit % tiles_x) * 8u + (lane & 7u), y = (unit / tiles_x) * 8u + (lane >> 3);
       valid = x < p.img_w && y < p.img_h;
       idx = y * p.img_w + x;
-      if (parts_log2 == 2u) lane_part = ((lane >> 2) & 1u) | ((lane >> 5) << 1);   // 4x4 quadrants
     }
-    valid = valid && (parts_log2 == 0u || lane_part == part);
     uint32_t wave_cost = 0;
     uint32_t c_node = 0, c_tri = 0, c_leaf = 0, c_hit = 0;  // instrumented build: this lane's counts
     if (valid) {
@@ -338,13 +326,8 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
       if (MODE == kModeTrace && p.rgba) reinterpret_cast<float4 *>(p.rgba)[idx] = color;
     }
     if (p.unit_cost) {
-      // iterations are counted wave-wide, so every lane that traced holds the same number; lanes that did not hold 0
-      uint32_t cost = wave_cost;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) cost = max(cost, static_cast<uint32_t>(__shfl_xor(static_cast<int>(cost), off)));
-      // the parts of a split unit add up (the buffer is zero before the launch): a unit that was worth
-      // splitting stays classified as heavy
-      if (lane == 0 && cost) atomicAdd(p.unit_cost + unit, cost);
+      const uint32_t cost = __builtin_amdgcn_readfirstlane(wave_cost);   // lane 0 always owns a ray
+      if (lane == 0) p.unit_cost[unit] = cost;
     }
     if (COUNT) {
       // one atomic per counter per wave, so the instrumented launch keeps the real launch's timing shape
@@ -379,23 +362,15 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
 // Counting sort of work units by cost bin (cost / 16, capped), costliest bin first, ascending unit index inside
 // a bin so neighbouring units stay neighbours.  One workgroup of 512 threads; thread t owns the contiguous run
 // [t*per, (t+1)*per) and reads it 32 keys at a time as eight independent 16-byte loads, so each pass costs a
-// handful of memory round trips instead of one per key.  unit_cost must be readable and writable up to 512*per
-// entries; it is left all zero for the launch that accumulates into it next.
-//
-// The order has `nslots` >= n entries.  Going down from the costliest bin, a bin's units are given four slots
-// each (then two) while the spare nslots - n slots last and the bin is at least `kSplitMinBin`; the rest of the
-// table is filled with kNoWork.
+// handful of memory round trips instead of one per key.  unit_cost must be readable up to 512*per entries.
 __device__ __forceinline__ uint32_t CostBin(uint32_t cost) { return min(cost >> 4, static_cast<uint32_t>(kFbBuckets - 1)); }
-constexpr uint32_t kSplitMinBin = 2;   // units cheaper than 32 wave iterations are never split
 
-__global__ void __launch_bounds__(512) BuildOrderKernel(uint32_t *unit_cost, uint32_t n, uint32_t per, uint32_t *order,
-                                                        uint32_t nslots)
+__global__ void __launch_bounds__(512) BuildOrderKernel(const uint32_t *unit_cost, uint32_t n, uint32_t per, uint32_t *order)
 {
   __shared__ uint32_t table[kFbBuckets * 512];   // [bin, costliest first][thread]: counts, then next free position
   __shared__ uint32_t partial[8];
-  __shared__ uint32_t bin_log2[kFbBuckets];      // log2(slots per unit) chosen for each bin row
   const uint32_t t = threadIdx.x, lo = t * per;
-  uint4 *keys4 = reinterpret_cast<uint4 *>(unit_cost + lo);   // per is a multiple of 32
+  const uint4 *keys4 = reinterpret_cast<const uint4 *>(unit_cost + lo);   // per is a multiple of 32
 #pragma unroll
   for (int b = 0; b < kFbBuckets; ++b) table[b * 512 + t] = 0;
   // no barrier needed yet: every thread only touches its own column of the table in this pass
@@ -414,10 +389,9 @@ __global__ void __launch_bounds__(512) BuildOrderKernel(uint32_t *unit_cost, uin
   __syncthreads();
   // exclusive scan over the flat table (bin-major, thread-minor), one bin row at a time: a wave-level scan by
   // lane shuffles plus the 8 wave totals, so every LDS access is either conflict-free or a broadcast
-  uint32_t base = 0;
   {
     const uint32_t lane = t & 63u, w = t >> 6;
-    uint32_t spare = nslots - n;
+    uint32_t base = 0;
     for (int b = 0; b < kFbBuckets; ++b) {
       const uint32_t v = table[b * 512 + t];
       uint32_t x = v;
@@ -435,26 +409,15 @@ __global__ void __launch_bounds__(512) BuildOrderKernel(uint32_t *unit_cost, uin
         before += k < w ? wt : 0u;
         total += wt;
       }
-      // every thread computes the same decision from the same totals
-      uint32_t lg = 0;
-      if (static_cast<uint32_t>(kFbBuckets - 1 - b) >= kSplitMinBin) {
-        if (3u * total <= spare) lg = 2;
-        else if (total <= spare) lg = 1;
-      }
-      spare -= ((1u << lg) - 1u) * total;
-      if (t == 0) bin_log2[b] = lg;
-      table[b * 512 + t] = base + ((before + x - v) << lg);
-      base += total << lg;
+      table[b * 512 + t] = base + before + x - v;
+      base += total;
       __syncthreads();
     }
   }
   for (uint32_t c = 0; c < per; c += 32u) {
     uint4 k[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      k[j] = keys4[c / 4u + j];
-      keys4[c / 4u + j] = make_uint4(0u, 0u, 0u, 0u);
-    }
+    for (int j = 0; j < 8; ++j) k[j] = keys4[c / 4u + j];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t v[4] = {k[j].x, k[j].y, k[j].z, k[j].w};
@@ -462,16 +425,14 @@ __global__ void __launch_bounds__(512) BuildOrderKernel(uint32_t *unit_cost, uin
       for (int e = 0; e < 4; ++e) {
         const uint32_t i = lo + c + 4u * j + e;
         if (i < n) {
-          const uint32_t row = kFbBuckets - 1 - CostBin(v[e]), lg = bin_log2[row];
-          uint32_t *cell = &table[row * 512 + t];
+          uint32_t *cell = &table[(kFbBuckets - 1 - CostBin(v[e])) * 512 + t];
           const uint32_t pos = *cell;
-          *cell = pos + (1u << lg);
-          for (uint32_t q = 0; q < (1u << lg); ++q) order[pos + q] = i | (q << kEntryPartShift) | (lg << kEntryLogShift);
+          *cell = pos + 1u;
+          order[pos] = i;
         }
       }
     }
   }
-  for (uint32_t i = base + t; i < nslots; i += 512u) order[i] = kNoWork;
 }
 
 __global__ void TriBatchKernel(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv)
@@ -521,12 +482,11 @@ hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode
 
 uint32_t BuildOrderKeysPerThread(uint32_t nunits) { return ((nunits + 511u) / 512u + 31u) / 32u * 32u; }
 
-hipError_t LaunchBuildOrder(uint32_t *unit_cost, uint32_t nunits, uint32_t *order, uint32_t nslots, hipStream_t stream)
+hipError_t LaunchBuildOrder(const uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream)
 {
-  if (nslots < nunits || nunits > kEntryUnitMask) return hipErrorInvalidValue;
   (void)hipGetLastError();
   hipLaunchKernelGGL(BuildOrderKernel, dim3(1), dim3(512), 0, stream, unit_cost, nunits, BuildOrderKeysPerThread(nunits),
-                     order, nslots);
+                     order);
   return hipGetLastError();
 }
 

@@ -297,16 +297,14 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
         dict(image_width=W, feedback=1),
         dict(image_width=0, feedback=1),
         dict(image_width=W, feedback=1, block_threads=64),
-        dict(image_width=W, feedback=1, block_threads=128, split_pct=0),
-        dict(image_width=W, feedback=1, split_pct=300),
-        dict(image_width=0, feedback=1, split_pct=50),
+        dict(image_width=W, feedback=1, block_threads=128),
         dict(image_width=W, leaf_pct=1),
         dict(image_width=W, leaf_pct=100),
         dict(image_width=W, leaf_pct=37, block_threads=128, width=4),
         dict(image_width=W, quantized=0, feedback=1, width=4),
     ]
     defaults = dict(width=2, quantized=1, block_threads=256, image_width=0, leaf_pct=50,
-                    centre_first=1, feedback=0, split_pct=12)
+                    centre_first=1, feedback=0)
     for cfg in settings:
         for k, v in {**defaults, **cfg}.items():
             scene.set_param(k, v)
