@@ -66,7 +66,25 @@ def parse():
     ap.add_argument("--quant", type=int, default=-1, help="1: 16-bit quantized boxes, 0: float boxes (-1 = library default)")
     ap.add_argument("--block", type=int, default=0, help="workgroup threads: 64, 128 or 256 (0 = library default)")
     ap.add_argument("--image-hint", type=int, default=1, help="declare the ray array as a W-wide image (8x8 tiles per wave)")
+    ap.add_argument("--feedback", type=int, default=1,
+                    help="1: each launch starts its work units costliest-first, by the costs measured two launches earlier")
     return ap.parse_args()
+
+
+def measured_traffic(workload, out_bytes, world):
+    """(GB per launch, file) from the newest profiles/r*/hbm_traffic.json that has this workload, else (None, None)."""
+    if world != 1:
+        return None, None
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    key = f"{workload}/out{out_bytes}"
+    for d in sorted((x for x in os.listdir(root) if x.startswith("r")), reverse=True) if os.path.isdir(root) else []:
+        path = os.path.join(root, d, "hbm_traffic.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                table = json.load(f)
+            if key in table:
+                return table[key]["gb_per_launch"], f"profiles/{d}/hbm_traffic.json"
+    return None, None
 
 
 def main():
@@ -99,6 +117,7 @@ def main():
         scene.set_param("block_threads", a.block)
     if W and a.workload != "tiles4k" and a.image_hint:
         scene.set_param("image_width", W)
+    scene.set_param("feedback", a.feedback)
     info = scene.info()
     box = bvh.root_box
 
@@ -198,6 +217,10 @@ def main():
             "node_bytes": node_b, "tri_bytes": info["tri_bytes"], "ray_in_bytes": 64, "hit_out_bytes": out_b,
             "hit_fraction": round(cnt["rays_hit"] / cnt["rays"], 4),
         }
+        # HBM-side bytes per launch from PMC counters: measured in separate rocprofv3 passes (tools/profile_gpu.sh),
+        # committed next to the kernel-trace summary, looked up here by workload and output record
+        roofline["traffic"], roofline["traffic_source"] = measured_traffic(a.workload, out_b, world)
+        roofline["traffic_unit"] = "GB per launch (2 x FETCH_SIZE + WRITE_SIZE)"
 
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
@@ -231,6 +254,8 @@ def main():
                        "name": a.workload, "rays_per_gpu": n_local, "rays_total": n_total, "triangles": len(mesh.faces),
                        "loader": "tolerant", "bvh": a.bvh, "bvh_width": width, "nodes": info["nodes4" if width == 4 else "nodes2"],
                        "hit_record": "64B RayIntersection" if out_b == 64 else "16B {id,t,u,v}",
+                       "dispatch_order": "costliest work unit first, from the costs measured two launches earlier" if a.feedback
+                       else "image centre first",
                        "parallelism": f"{world} x frame-parallel" if a.workload != "tiles4k" else f"{world} x interleaved {a.tile}x{a.tile} tiles + RCCL gather"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

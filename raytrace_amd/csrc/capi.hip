@@ -227,6 +227,12 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     }
     a.unit_cost = s->d_fb_cost[fb_slot];
   }
+  if (s->feedback == 1 && count && s->fb_launch >= 1u && s->fb_ntasks == a.ntasks && s->fb_n == a.n && s->fb_img_w == a.img_w) {
+    // instrumented launch: follow the newest cost-sorted order, read-only
+    const int newest = static_cast<int>((s->fb_launch - 1u) & 1u);
+    RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[newest], 0));
+    a.order = s->d_fb_order[newest];
+  }
   if (static_cast<size_t>(a.stack_entries) * 1024u > 160u * 1024u)
     return Fail(RT_ERR_INVALID, "bvh too deep for the LDS traversal stack");
   {

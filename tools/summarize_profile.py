@@ -43,6 +43,10 @@ if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
     rd, wr = m["FETCH_SIZE"] * 1024, m["WRITE_SIZE"] * 1024
     print(f"\nHBM-side bytes per launch: read {rd/1e6:.1f} MB as counted, {2*rd/1e6:.1f} MB with the gfx950 x2 "
           f"wide-read correction; written {wr/1e6:.1f} MB")
+    import json
+    with open(os.path.join(out, "hbm_traffic_entry.json"), "w") as f:
+        json.dump({"gb_per_launch": round((2 * rd + wr) / 1e9, 4), "fetch_size_kb": m["FETCH_SIZE"], "write_size_kb": m["WRITE_SIZE"],
+                   "note": "2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE, mean per launch"}, f)
 if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
     print(f"L2 hit rate: {m['TCC_HIT_sum']/(m['TCC_HIT_sum']+m['TCC_MISS_sum']):.4f}")
 if "SQ_ACTIVE_INST_VALU" in m and "SQ_BUSY_CYCLES" in m:

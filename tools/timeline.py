@@ -17,6 +17,10 @@ for kv in cfg.split(","):
         scene.set_param(k, W if v == "W" else int(v))
 rays = rt.primary_rays(W, H, rt.frame_camera(bvh.root_box, W, H))
 d = torch.from_numpy(rays).cuda()
+out = torch.empty((len(rays), 16), dtype=torch.float32, device="cuda")
+for _ in range(4):   # lets a cost-feedback order settle before the instrumented launch follows it
+    scene.intersect_async(d.data_ptr(), len(rays), out.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
 for _ in range(4):
     tl = scene.wave_timeline(d.data_ptr(), len(rays))
 long = (tl[:, 1] - tl[:, 0]) > 100  # > 1 us: waves that actually traced
@@ -35,4 +39,6 @@ print("  waves alive per 5% time slice:", conc)
 last = [float(end[tl[:, 3] == x].max()) for x in np.unique(tl[:, 3])]
 print("  last wave end per XCC (us):", [round(x, 1) for x in last])
 order = np.argsort(start)
+top = np.argsort(-life)[:8]
+print("  longest waves (start us, life us):", [(round(float(start[i]), 1), round(float(life[i]), 1)) for i in top])
 print("  launch rate: first 10%% of waves started within %.1f us; median start %.1f us; last start %.1f us" % (start[order][len(order)//10], np.median(start), start.max()))
