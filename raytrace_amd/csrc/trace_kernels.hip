@@ -170,6 +170,21 @@ __device__ __forceinline__ uint32_t Step4Q(const KernelArgs &p, const RayCtxQ &q
 
 __device__ __forceinline__ float Dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
+// Ray record handled by `lane` of the wave that owns work unit `unit`; false if the lane falls off the ray set.
+// Linear: the unit is 64 consecutive records.  Image: the unit is an 8x8 pixel tile (the reference launches 8x8
+// work-groups too, img_main.cpp:457-461), which keeps the 64 rays of a wave on neighbouring paths through the tree.
+__device__ __forceinline__ bool RayOfLane(const KernelArgs &p, uint32_t unit, uint32_t lane, uint32_t &idx)
+{
+  if (p.img_w) {
+    const uint32_t tiles_x = (p.img_w + 7u) >> 3;
+    const uint32_t x = (unit % tiles_x) * 8u + (lane & 7u), y = (unit / tiles_x) * 8u + (lane >> 3);
+    idx = y * p.img_w + x;
+    return x < p.img_w && y < p.img_h;
+  }
+  idx = unit * 64u + lane;
+  return idx < p.n;
+}
+
 template <int WIDTH, bool QUANT, int MODE, bool COUNT>
 __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
 {
@@ -185,19 +200,11 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
     // Which work unit this wave takes: the k-th entry of the dispatch order.  The order comes from an earlier
     // launch's measured costs (costliest first, so the few long-running waves start first instead of being the
     // last ones alive) or, failing that, runs from the image centre out.
-    // Ray owned by this lane.  Linear: the unit is 64 consecutive records.  Image: the unit is an 8x8 pixel
-    // tile (the reference launches 8x8 work-groups too, img_main.cpp:457-461), which keeps the 64 rays of a
-    // wave on neighbouring paths through the tree.
     uint32_t unit = base >> 6;
     if (p.order) unit = p.order[unit];
-    uint32_t idx = unit * 64u + lane;
-    bool valid = idx < p.n;
-    if (p.img_w) {
-      const uint32_t tiles_x = (p.img_w + 7u) >> 3;
-      const uint32_t x = (unit % tiles_x) * 8u + (lane & 7u), y = (unit / tiles_x) * 8u + (lane >> 3);
-      valid = x < p.img_w && y < p.img_h;
-      idx = y * p.img_w + x;
-    }
+    uint32_t idx;
+    const bool valid = RayOfLane(p, unit, lane, idx);
+    float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0, rec3 = rec0;   // this lane's output record
     uint32_t wave_cost = 0;
     uint32_t c_node = 0, c_tri = 0, c_leaf = 0, c_hit = 0;  // instrumented build: this lane's counts
     if (valid) {
@@ -315,15 +322,28 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
             }
           }
         }
-        if (p.hits) {
-          float4 *op = reinterpret_cast<float4 *>(p.hits + idx);
-          op[0] = out_o;
-          op[1] = out_d;
-          op[2] = out_n;
-          op[3] = make_float4(out_u, out_v, __uint_as_float(best.id), best.t);
-        }
+        rec0 = out_o; rec1 = out_d; rec2 = out_n;
+        rec3 = make_float4(out_u, out_v, __uint_as_float(best.id), best.t);
       }
       if (MODE == kModeTrace && p.rgba) reinterpret_cast<float4 *>(p.rgba)[idx] = color;
+    }
+    if (p.hits) {
+      // 64-byte records, one per lane: written straight from the lanes, every store instruction would scatter 64
+      // 16-byte pieces over 32 cache lines.  The wave's traversal stack is idle by now, so the records are
+      // exchanged through it and each of the four stores covers 16 whole records (1 KB runs in linear mode,
+      // 512-byte rows of an 8x8 tile in image mode).
+      float4 *tile = reinterpret_cast<float4 *>(lds_stack + wave * p.stack_entries * 64u);   // [lane][quarter]
+      tile[lane * 4u + 0u] = rec0; tile[lane * 4u + 1u] = rec1; tile[lane * 4u + 2u] = rec2; tile[lane * 4u + 3u] = rec3;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t src = k * 16u + (lane >> 2), quarter = lane & 3u;
+        const float4 v = tile[src * 4u + quarter];
+        uint32_t src_idx;
+        if (RayOfLane(p, unit, src, src_idx)) reinterpret_cast<float4 *>(p.hits + src_idx)[quarter] = v;
+      }
     }
     if (p.unit_cost) {
       const uint32_t cost = __builtin_amdgcn_readfirstlane(wave_cost);   // lane 0 always owns a ray
