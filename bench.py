@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--quant", type=int, default=-1, help="1: 16-bit quantized boxes, 0: float boxes (-1 = library default)")
     ap.add_argument("--block", type=int, default=0, help="workgroup threads: 64, 128 or 256 (0 = library default)")
     ap.add_argument("--image-hint", type=int, default=1, help="declare the ray array as a W-wide image (8x8 tiles per wave)")
+    ap.add_argument("--waves-per-cu", type=int, default=-1, help="resident-wave cap per CU (-1 = library default)")
     ap.add_argument("--feedback", type=int, default=1,
                     help="1: each launch starts its work units costliest-first, by the costs measured two launches earlier")
     return ap.parse_args()
@@ -118,6 +119,8 @@ def main():
     if W and a.workload != "tiles4k" and a.image_hint:
         scene.set_param("image_width", W)
     scene.set_param("feedback", a.feedback)
+    if a.waves_per_cu >= 0:
+        scene.set_param("waves_per_cu", a.waves_per_cu)
     info = scene.info()
     box = bvh.root_box
 

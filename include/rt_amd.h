@@ -115,6 +115,8 @@ int rt_scene_info(const rt_scene *s, uint64_t info[8]);
  *   "leaf_pct"       1..100: a wave switches from node steps to leaf steps once this share of its busy lanes
  *                    holds a leaf; 100 = descend until every lane does.
  *   "block_threads"  64, 128 or 256.
+ *   "waves_per_cu"   0..64: cap on resident waves per CU, held by sizing the traversal stack in LDS (default 0 =
+ *                    whatever registers and the tree depth allow).
  *   "extra_stack"    diagnostic: extra traversal-stack entries per lane (lowers occupancy).
  * Calls on one scene must not overlap in time from different host threads (the scene caches launch state);
  * the launches themselves may go to any streams. */
@@ -161,7 +163,7 @@ int rt_scene_count_fetches(const rt_scene *s, const rt_ray_isect *rays_host, siz
  * models one batch of 64 rays per wave; refill = k models a wave that takes new rays for its idle
  * lanes whenever k or more lanes have finished.  Computes no hits. */
 int rt_scene_wave_model(const rt_scene *s, const rt_ray_isect *rays_host, size_t n, unsigned image_width, unsigned refill,
-                        size_t max_waves, int policy, uint64_t out[11]);
+                        size_t max_waves, int policy, uint64_t out[12]);
 /* The same counters taken on the device by an instrumented build of the kernel over all n
  * rays (device pointer): counts[0..3] as above, counts[4] = n. */
 int rt_scene_count_fetches_device(const rt_scene *s, const void *rays_dev, size_t n, uint64_t counts[5]);

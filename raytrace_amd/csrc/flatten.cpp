@@ -26,14 +26,14 @@ inline uint32_t QuantDown(float v, float lo, float step)
 {
   double q = std::floor((static_cast<double>(v) - lo) / step);
   while (q > 0 && lo + q * static_cast<double>(step) > v) q -= 1;
-  q -= 1;
+  q -= 2;  // one cell for the grid arithmetic, one for the traversal's biased plane constant
   return static_cast<uint32_t>(std::min(65535.0, std::max(0.0, q)));
 }
 inline uint32_t QuantUp(float v, float lo, float step)
 {
   double q = std::ceil((static_cast<double>(v) - lo) / step);
   while (q < 65535 && lo + q * static_cast<double>(step) < v) q += 1;
-  q += 1;
+  q += 2;
   return static_cast<uint32_t>(std::min(65535.0, std::max(0.0, q)));
 }
 
@@ -424,6 +424,16 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
         if (policy >= 2 && n_leaf * 100u >= static_cast<uint32_t>(policy) * (n_inner + n_leaf)) break;
         m.wave_node_steps++;
         m.lane_node_steps += n_inner;
+        {
+          uint32_t first_ref = kDoneRef;
+          bool same = true;
+          for (auto &l : lanes)
+            if (!(l.cur & kLeafBit)) {
+              if (first_ref == kDoneRef) first_ref = l.cur;
+              else if (l.cur != first_ref) same = false;
+            }
+          if (same) m.uniform_node_steps++;
+        }
         for (auto &l : lanes) {
           if (l.cur & kLeafBit) continue;
           uint32_t hit_ref[4]; float hit_t[4]; int nh = 0;

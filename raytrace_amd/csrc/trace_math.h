@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -78,51 +79,92 @@ RT_HD bool SlabTest(const RayCtx &r, float lox, float loy, float loz, float hix,
 // hi rounded up on the host, so the decoded box always contains the float box.  A child costs
 // 16 bytes (three dwords + reference) instead of 28, which halves the record fetches the texture
 // path has to serve per traversal step.  The slab distances come straight from the grid indices:
-//   t = (grid_lo + q*step - o') * inv = q * (step*inv) + (grid_lo - o') * inv = fma(q, A, B)
-// with A and B per-ray constants; the rounding of A, B and the fma is covered by the same outward
-// padding of o' that SetupRay applies.
+//   t = (grid_lo + q*step - o') * inv = q * (step*inv) + (grid_lo - o') * inv = q*A + B
+// with A and B per-ray constants.  The index never goes through an int-to-float conversion: the
+// 16 bits are dropped into the mantissa of 2^23 (one byte permute picks the near or the far half
+// of the axis word and supplies the exponent), which reads as the float F = 2^23 + q exactly, and
+//   t = fma(F, A, B - 2^23*A).
+// Rounding B - 2^23*A once costs at most half a grid cell of plane position on top of the
+// roundings of A, B and the fma that the outward padding of o' already covers; the host rounds
+// the boxes outward by one more cell for it.
 struct QuantGrid {
   float lo[3];
   float step[3];
 };
 
+constexpr uint32_t kBiasBits = 0x4B000000u;   // 2^23 as a float
+constexpr float kBias = 8388608.0f;
+// Byte selectors for {axis word (bytes 4..7), kBiasBits (bytes 0..3)}: result = bias exponent | chosen half.
+constexpr uint32_t kSelLoHalf = 0x03020504u, kSelHiHalf = 0x03020706u;
+
 struct RayCtxQ {
   float ax, ay, az;        // step * inv
-  float bnx, bny, bnz;     // (grid_lo - (o + sgn*pad)) * inv : near planes
-  float bfx, bfy, bfz;     // (grid_lo - (o - sgn*pad)) * inv : far planes
-  uint32_t rx, ry, rz;     // 16 if the direction component is negative (near plane = hi half), else 0
+  float bnx, bny, bnz;     // (grid_lo - (o + sgn*pad)) * inv - 2^23 * a : near planes
+  float bfx, bfy, bfz;     // (grid_lo - (o - sgn*pad)) * inv - 2^23 * a : far planes
+  uint32_t nx, ny, nz;     // selector of the near plane's half of the axis word
+  uint32_t fx, fy, fz;     // selector of the far plane's half
 };
+
+RT_HD void SetupRayQAxis(float o, float inv, bool neg, float pad, float glo, float step, float &a, float &bn, float &bf,
+                         uint32_t &seln, uint32_t &self)
+{
+  // keeps 2^23 * |a| finite for grids coarser than one unit per cell
+  const float lim = kInvClamp / fmaxf(step, 1.f);
+  inv = fminf(fmaxf(inv, -lim), lim);
+  const float p = neg ? -pad : pad;
+  a = step * inv;
+  bn = fmaf(-kBias, a, (glo - (o + p)) * inv);
+  bf = fmaf(-kBias, a, (glo - (o - p)) * inv);
+  seln = neg ? kSelHiHalf : kSelLoHalf;
+  self = neg ? kSelLoHalf : kSelHiHalf;
+}
 
 RT_HD void SetupRayQ(RayCtxQ &q, const RayCtx &r, const QuantGrid &g, float scale)
 {
   const float pad = kPadFactor * (fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz)) + scale);
-  const float px = r.sx ? -pad : pad, py = r.sy ? -pad : pad, pz = r.sz ? -pad : pad;
-  q.ax = g.step[0] * r.ix; q.ay = g.step[1] * r.iy; q.az = g.step[2] * r.iz;
-  q.bnx = (g.lo[0] - (r.ox + px)) * r.ix; q.bny = (g.lo[1] - (r.oy + py)) * r.iy; q.bnz = (g.lo[2] - (r.oz + pz)) * r.iz;
-  q.bfx = (g.lo[0] - (r.ox - px)) * r.ix; q.bfy = (g.lo[1] - (r.oy - py)) * r.iy; q.bfz = (g.lo[2] - (r.oz - pz)) * r.iz;
-  q.rx = r.sx ? 16u : 0u; q.ry = r.sy ? 16u : 0u; q.rz = r.sz ? 16u : 0u;
+  SetupRayQAxis(r.ox, r.ix, r.sx, pad, g.lo[0], g.step[0], q.ax, q.bnx, q.bfx, q.nx, q.fx);
+  SetupRayQAxis(r.oy, r.iy, r.sy, pad, g.lo[1], g.step[1], q.ay, q.bny, q.bfy, q.ny, q.fy);
+  SetupRayQAxis(r.oz, r.iz, r.sz, pad, g.lo[2], g.step[2], q.az, q.bnz, q.bfz, q.nz, q.fz);
 }
 
-RT_HD uint32_t Rot32(uint32_t v, uint32_t s)
+// 2^23 + (the half of `word` that `sel` names), as a float.
+RT_HD float BiasedPlane(uint32_t word, uint32_t sel)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_alignbit(v, v, s);
+  return __uint_as_float(__builtin_amdgcn_perm(word, kBiasBits, sel));
 #else
-  return s ? ((v >> s) | (v << (32u - s))) : v;
+  const uint32_t bits = kBiasBits | (sel == kSelLoHalf ? (word & 0xFFFFu) : (word >> 16));
+  float f;
+  std::memcpy(&f, &bits, sizeof f);
+  return f;
 #endif
 }
 
-// cx, cy, cz: the three packed axis words of one child.  Same acceptance rule as SlabTest.
+// Entry (clamped at 0) and exit (clamped at tbest) distances from already biased plane values.
+RT_HD void SlabRangeBiased(const RayCtxQ &q, float nx, float ny, float nz, float fx, float fy, float fz, float tbest,
+                           float &tmin, float &tmax)
+{
+  const float t0x = fmaf(nx, q.ax, q.bnx), t1x = fmaf(fx, q.ax, q.bfx);
+  const float t0y = fmaf(ny, q.ay, q.bny), t1y = fmaf(fy, q.ay, q.bfy);
+  const float t0z = fmaf(nz, q.az, q.bnz), t1z = fmaf(fz, q.az, q.bfz);
+  tmin = fmaxf(fmaxf(fmaxf(t0x, t0y), t0z), 0.f);
+  tmax = fminf(fminf(fminf(t1x, t1y), t1z), tbest);
+}
+
+// Same acceptance rule as SlabTest.
+RT_HD bool SlabTestBiased(const RayCtxQ &q, float nx, float ny, float nz, float fx, float fy, float fz, float tbest,
+                          float &tenter)
+{
+  float tmax;
+  SlabRangeBiased(q, nx, ny, nz, fx, fy, fz, tbest, tenter, tmax);
+  return tenter <= tmax;
+}
+
+// cx, cy, cz: the three packed axis words of one child.
 RT_HD bool SlabTestQ(const RayCtxQ &q, uint32_t cx, uint32_t cy, uint32_t cz, float tbest, float &tenter)
 {
-  const uint32_t wx = Rot32(cx, q.rx), wy = Rot32(cy, q.ry), wz = Rot32(cz, q.rz);  // low half = near plane
-  const float t0x = fmaf(static_cast<float>(wx & 0xFFFFu), q.ax, q.bnx), t1x = fmaf(static_cast<float>(wx >> 16), q.ax, q.bfx);
-  const float t0y = fmaf(static_cast<float>(wy & 0xFFFFu), q.ay, q.bny), t1y = fmaf(static_cast<float>(wy >> 16), q.ay, q.bfy);
-  const float t0z = fmaf(static_cast<float>(wz & 0xFFFFu), q.az, q.bnz), t1z = fmaf(static_cast<float>(wz >> 16), q.az, q.bfz);
-  const float tmin = fmaxf(fmaxf(fmaxf(t0x, t0y), t0z), 0.f);
-  const float tmax = fminf(fminf(fminf(t1x, t1y), t1z), tbest);
-  tenter = tmin;
-  return tmin <= tmax;
+  return SlabTestBiased(q, BiasedPlane(cx, q.nx), BiasedPlane(cy, q.ny), BiasedPlane(cz, q.nz), BiasedPlane(cx, q.fx),
+                        BiasedPlane(cy, q.fy), BiasedPlane(cz, q.fz), tbest, tenter);
 }
 
 // Closest-hit triangle test on a pre-gathered record (a, e1 = b - a, e2 = c - a).
