@@ -11,6 +11,8 @@ Workloads (BASELINE.json configs):
   bunny1080    bunny.obj 1920x1080 primary rays
   dragon4k     dragon.obj 3840x2160 primary rays
   ao           bunny_big.obj incoherent AO-style rays (--rays, default 16 Mi per GPU)
+  mirror5      cube_mirror_test.obj 1920x1080: one step = the primary pass + four reflection passes of the
+               full `trace` kernel (rt_trace_pass, records ping-ponged on the device); rays counted = 5 x W x H
   tiles4k      dragon.obj 3840x2160 split by interleaved 64x64 tiles over the ranks, with the
                compact framebuffer gathered to rank 0 over RCCL (strong scaling; the gather is
                timed inside the step and also reported on its own)
@@ -46,6 +48,7 @@ WORKLOADS = {
     "dragon4k": ("dragon.obj", 3840, 2160),
     "tiles4k": ("dragon.obj", 3840, 2160),
     "ao": ("bunny_big.obj", 0, 0),
+    "mirror5": ("cube_mirror_test.obj", 1920, 1080),
 }
 
 
@@ -105,7 +108,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     model, W, H = WORKLOADS[a.workload]
-    mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "tolerant")
+    mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "reference" if a.workload == "mirror5" else "tolerant")
     bvh = rt.BVH(mesh, a.bvh)
     scene = rt.Scene(mesh, bvh, device=local, width=4 if a.width == 4 else 2)
     if a.width in (2, 4):
@@ -142,7 +145,7 @@ def main():
             own = None
         n_local = len(rays_h)
     rays_d = torch.from_numpy(rays_h).cuda()
-    full_out = a.out == "full"
+    full_out = a.out == "full" or a.workload == "mirror5"
     hits_d = torch.empty((n_local, 16 if full_out else 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -153,8 +156,21 @@ def main():
             gather_bufs = [torch.empty((c, 4), dtype=torch.float32, device="cuda") for c in counts]
         hits16_d = torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
 
+    passes = 5 if a.workload == "mirror5" else 1
+    if a.workload == "mirror5":
+        pong = torch.empty((n_local, 16), dtype=torch.float32, device="cuda")
+        rgba_d = torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
+        cam = np.eye(4, dtype=np.float32)
+
     def step():
-        if a.workload == "tiles4k" and world > 1:
+        if a.workload == "mirror5":
+            # pass 0 reads the primary table; passes 1..4 reflect the previous pass's records (ping-pong)
+            scene.trace_pass(rays_d.data_ptr(), hits_d.data_ptr(), rgba_d.data_ptr(), n_local, cam, 0, stream)
+            src, dst = hits_d, pong
+            for _ in range(4):
+                scene.trace_pass(src.data_ptr(), dst.data_ptr(), rgba_d.data_ptr(), n_local, cam, 1, stream)
+                src, dst = dst, src
+        elif a.workload == "tiles4k" and world > 1:
             scene.intersect_async(rays_d.data_ptr(), n_local, None, hits16_d.data_ptr(), stream)
             # one exchange: compact hit tiles to rank 0 (point-to-point sends, not a ring)
             if rank == 0:
@@ -187,6 +203,7 @@ def main():
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1) / max(1, a.steps)  # mean launch duration on the launch stream
+    dev_ms /= passes
     if dist:
         tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -196,12 +213,15 @@ def main():
         n_total = int(nn.item())
     else:
         n_total = n_local
+    n_total *= passes
     ms_per_step = wall * 1e3 / max(1, a.steps)
     mrays = n_total / (ms_per_step * 1e-3) / 1e6
 
     if rank == 0:
         # ---- algorithmic bytes per ray: records the traversal fetches, counted exactly ----
         width = a.width if a.width in (2, 4) else 2
+        if a.workload == "mirror5":
+            scene.set_param("feedback", 0)   # the counting launch below is a primary pass only
         cnt = scene.count_fetches_device(rays_d.data_ptr(), n_local)
         stride = max(1, n_local // 8192)
         cnt_cpu = scene.count_fetches(rays_h, stride)
@@ -209,6 +229,10 @@ def main():
         n_node, n_tri = cnt["nodes"] / cnt["rays"], cnt["tris"] / cnt["rays"]
         out_b = 64 if (full_out and not (a.workload == "tiles4k" and world > 1)) else 16
         bytes_per_ray = 64 + out_b + n_node * node_b + n_tri * info["tri_bytes"]
+        if a.workload == "mirror5":
+            # reflection passes trace rays that exist only inside the kernel: their records are not counted, so
+            # the figure below prices every pass at the streams alone (record in, record out, RGBA pixel)
+            bytes_per_ray = 64 + 64 + 16
         achieved = bytes_per_ray * n_local / (dev_ms * 1e-3) / 1e9
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -226,7 +250,7 @@ def main():
         roofline["traffic_unit"] = "GB per launch (2 x FETCH_SIZE + WRITE_SIZE)"
 
         cpu = None
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload != "mirror5":
             import oracle  # the CPU checker, used here only as the timed baseline
             if a.workload == "ao":
                 sample = rays_h[:: max(1, n_local // 16384)]
@@ -253,7 +277,8 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong" if a.workload == "tiles4k" else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{model} {W}x{H} primary rays" if W else f"{model} {n_local} AO rays per GPU",
+            "config": {"workload": f"{model} {W}x{H} primary pass + 4 reflection passes (full trace kernel)" if a.workload == "mirror5"
+                       else f"{model} {W}x{H} primary rays" if W else f"{model} {n_local} AO rays per GPU",
                        "name": a.workload, "rays_per_gpu": n_local, "rays_total": n_total, "triangles": len(mesh.faces),
                        "loader": "tolerant", "bvh": a.bvh, "bvh_width": width, "nodes": info["nodes4" if width == 4 else "nodes2"],
                        "hit_record": "64B RayIntersection" if out_b == 64 else "16B {id,t,u,v}",
