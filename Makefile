@@ -14,7 +14,7 @@ HOSTFLAGS = -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
 HIPFLAGS = -std=c++17 -O3 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
            -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -Wall -Wno-unused-parameter -Iinclude
 
-HOST_SRCS = obj_loader centroid_bvh raygen flatten framebuffer
+HOST_SRCS = obj_loader centroid_bvh sah_bvh raygen flatten framebuffer
 HIP_SRCS = trace_kernels capi
 HOST_OBJS = $(foreach s,$(HOST_SRCS),$(BUILD)/$(s).o)
 HIP_OBJS = $(foreach s,$(HIP_SRCS),$(BUILD)/$(s).o)

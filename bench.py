@@ -60,9 +60,12 @@ def parse():
     ap.add_argument("--workload", default="dragon1080", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=int(os.environ.get("RT_WIDTH", "0")), help="2 or 4 (0 = library default)")
     ap.add_argument("--rays", type=int, default=16 * 1024 * 1024, help="ray count for --workload ao")
-    ap.add_argument("--bvh", default="fixed", choices=["fixed", "reference"])
+    ap.add_argument("--bvh", default="sah", choices=["fixed", "reference", "sah"],
+                    help="tree handed to rt_scene_create: the reference's centroid build as written (reference), with its "
+                         "centroid indexing repaired (fixed), or the surface-area build in the same node format (sah)")
     ap.add_argument("--out", default="full", choices=["full", "compact"], help="64-byte hit records or 16-byte {id,t,u,v}")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-compare", action="store_true", help="skip the extra timing on the centroid tree")
     ap.add_argument("--cpu-stride", type=int, default=4, help="sub-grid stride (both axes) of the CPU baseline sample")
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--extra-stack", type=int, default=0, help="diagnostic: extra LDS per lane to lower occupancy")
@@ -249,6 +252,30 @@ def main():
         roofline["traffic"], roofline["traffic_source"] = measured_traffic(a.workload, out_b, world)
         roofline["traffic_unit"] = "GB per launch (2 x FETCH_SIZE + WRITE_SIZE)"
 
+        # the same launch on the reference's own (repaired) centroid tree, for comparison
+        centroid = None
+        if world == 1 and a.bvh == "sah" and not a.no_compare and a.workload in ("dragon1080", "bunny1080", "dragon4k"):
+            bvh_c = rt.BVH(mesh, "fixed")
+            scene_c = rt.Scene(mesh, bvh_c, device=local, width=4 if a.width == 4 else 2)
+            for k, v in (("quantized", a.quant), ("block_threads", a.block)):
+                if v > 0 or (k == "quantized" and v == 0):
+                    scene_c.set_param(k, v)
+            if a.image_hint:
+                scene_c.set_param("image_width", W)
+            scene_c.set_param("feedback", a.feedback)
+            for _ in range(a.warmup):
+                scene_c.intersect_async(rays_d.data_ptr(), n_local, hits_d.data_ptr() if full_out else None,
+                                        None if full_out else hits_d.data_ptr(), stream)
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            for _ in range(a.steps):
+                scene_c.intersect_async(rays_d.data_ptr(), n_local, hits_d.data_ptr() if full_out else None,
+                                        None if full_out else hits_d.data_ptr(), stream)
+            torch.cuda.synchronize()
+            cms = (time.perf_counter() - c0) * 1e3 / max(1, a.steps)
+            centroid = {"bvh": "fixed", "ms_per_step": round(cms, 4), "value": round(n_local / (cms * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
+            scene_c.close()
+
         cpu = None
         if world == 1 and not a.no_cpu_baseline and a.workload != "mirror5":
             import oracle  # the CPU checker, used here only as the timed baseline
@@ -285,7 +312,7 @@ def main():
                        "dispatch_order": "costliest work unit first, from the costs measured two launches earlier" if a.feedback
                        else "image centre first",
                        "parallelism": f"{world} x frame-parallel" if a.workload != "tiles4k" else f"{world} x interleaved {a.tile}x{a.tile} tiles + RCCL gather"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "same_launch_on_centroid_tree": centroid,
         }
         print(json.dumps(line), flush=True)
     if dist:

@@ -373,7 +373,7 @@ void rt_mesh_destroy(rt_mesh *m) { delete m; }
 int rt_bvh_build(const rt_face *faces, const rt_vec3 *verts, size_t ntris, size_t nverts, unsigned mode, rt_bvh **out)
 {
   if (!out || !faces || !verts) return Fail(RT_ERR_INVALID, "null argument");
-  if (mode > RT_BVH_FIXED) return Fail(RT_ERR_INVALID, "unknown bvh mode");
+  if (mode > RT_BVH_SAH) return Fail(RT_ERR_INVALID, "unknown bvh mode");
   if (ntris == 0 || nverts == 0) return Fail(RT_ERR_INVALID, "bvh build needs at least one triangle");
   for (size_t i = 0; i < ntris; ++i)
     if (faces[i].s[0] >= nverts || faces[i].s[1] >= nverts || faces[i].s[2] >= nverts)
@@ -381,7 +381,8 @@ int rt_bvh_build(const rt_face *faces, const rt_vec3 *verts, size_t ntris, size_
   rt_bvh *b = new (std::nothrow) rt_bvh;
   if (!b) return Fail(RT_ERR_NOMEM, "out of memory");
   try {
-    rt::CentroidBVHBuild(&b->bvh, faces, verts, ntris, nverts, static_cast<rt::BvhMode>(mode));
+    if (mode == RT_BVH_SAH) rt::SahBVHBuild(&b->bvh, faces, verts, ntris, nverts);
+    else rt::CentroidBVHBuild(&b->bvh, faces, verts, ntris, nverts, static_cast<rt::BvhMode>(mode));
   } catch (const std::exception &ex) {
     delete b;
     return Fail(RT_ERR_NOMEM, std::string("bvh build failed: ") + ex.what());

@@ -72,6 +72,8 @@ struct CentroidBVH {
 
 void CentroidBVHBuild(CentroidBVH *bvh, rt_face const *triangles, rt_vec3 const *verts, size_t tricount,
                       size_t vertcount, BvhMode mode);
+// Same output format, topology from the binned surface-area heuristic (sah_bvh.cpp).
+void SahBVHBuild(CentroidBVH *bvh, rt_face const *triangles, rt_vec3 const *verts, size_t tricount, size_t vertcount);
 
 // ---- ray generators ---------------------------------------------------------
 // Primary-ray table of render_client/img_main.cpp:253-267 for a W x H image;

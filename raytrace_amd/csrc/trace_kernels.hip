@@ -332,15 +332,18 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
       // 16-byte pieces over 32 cache lines.  The wave's traversal stack is idle by now, so the records are
       // exchanged through it and each of the four stores covers 16 whole records (1 KB runs in linear mode,
       // 512-byte rows of an 8x8 tile in image mode).
-      float4 *tile = reinterpret_cast<float4 *>(lds_stack + wave * p.stack_entries * 64u);   // [lane][quarter]
-      tile[lane * 4u + 0u] = rec0; tile[lane * 4u + 1u] = rec1; tile[lane * 4u + 2u] = rec2; tile[lane * 4u + 3u] = rec3;
+      // [record][quarter ^ swizzle(record)]: the swizzle spreads the 64-byte-strided writes over all banks
+      float4 *tile = reinterpret_cast<float4 *>(lds_stack + wave * p.stack_entries * 64u);
+      const uint32_t wsw = (lane >> 2) & 3u;
+      tile[lane * 4u + (0u ^ wsw)] = rec0; tile[lane * 4u + (1u ^ wsw)] = rec1;
+      tile[lane * 4u + (2u ^ wsw)] = rec2; tile[lane * 4u + (3u ^ wsw)] = rec3;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (uint32_t k = 0; k < 4u; ++k) {
         const uint32_t src = k * 16u + (lane >> 2), quarter = lane & 3u;
-        const float4 v = tile[src * 4u + quarter];
+        const float4 v = tile[src * 4u + (quarter ^ ((src >> 2) & 3u))];
         uint32_t src_idx;
         if (RayOfLane(p, unit, src, src_idx)) reinterpret_cast<float4 *>(p.hits + src_idx)[quarter] = v;
       }

@@ -73,7 +73,7 @@ def test_node_for_node_equal_to_reference_builder(rt, oracle, model, loader):
     assert diff.size == 0, f"first differing (node, word): {diff[:5].tolist()}"
 
 
-@pytest.mark.parametrize("mode", ["reference", "fixed"])
+@pytest.mark.parametrize("mode", ["reference", "fixed", "sah"])
 @pytest.mark.parametrize("model", ["teapot.obj", "cube.obj", "bunny.obj"])
 def test_tree_properties(rt, model, mode):
     m = rt.Mesh.load_obj(os.path.join(MODELS, model), "tolerant")
@@ -107,8 +107,35 @@ def test_small_and_degenerate_scenes(rt):
     faces = np.zeros((9, 8), np.uint32)
     faces[:, :3] = (0, 1, 2)
     m = rt.Mesh.from_arrays(verts, faces)
-    b = rt.BVH(m, "fixed")
-    assert b.fallback_splits >= 1 and b.leafcount >= 3
+    for mode in ("fixed", "sah"):
+        b = rt.BVH(m, mode)
+        assert b.fallback_splits >= 1 and b.leafcount >= 3
+        tris = np.concatenate([b.nodes[i, :b.nodes[i, 4]] for i in np.flatnonzero(b.nodes[:, 16] == 1)])
+        assert np.array_equal(np.sort(tris), np.arange(9))
+    assert len(rt.BVH(sq, "sah").nodes) == 3      # four or fewer triangles: the reference's three-node layout
     with pytest.raises(rt.RtError):
         bad = faces.copy(); bad[0, 0] = 99
         rt.BVH(rt.Mesh.from_arrays(verts, bad), "fixed")
+
+
+def test_sah_tree_is_cheaper_to_traverse_and_flattens(rt):
+    """Same node format, better topology: the re-flattening accepts it, every inner box contains its children,
+    and the traversal restatement opens fewer boxes and tests fewer triangles than on the centroid tree."""
+    m = rt.Mesh.load_obj(os.path.join(MODELS, "bunny.obj"), "tolerant")
+    fixed, sah = rt.BVH(m, "fixed"), rt.BVH(m, "sah")
+    n = sah.nodes
+    boxes = n[:, 8:16].view(np.float32)
+    inner = np.flatnonzero(n[:, 16] == 0)
+    for c in (n[inner, 4], n[inner, 5]):
+        # (an exactly flat child box is given 0.01 of thickness, as the reference does)
+        assert np.all(boxes[c, 0:3] >= boxes[inner, 0:3]) and np.all(boxes[c, 4:7] <= boxes[inner, 4:7] + np.float32(0.0101))
+    origin = rt.frame_camera(fixed.root_box, 320, 240)
+    rays = rt.primary_rays(320, 240, origin)
+    cost = []
+    for b in (fixed, sah):
+        sc = rt.Scene(m, b, device=-1)
+        c = sc.count_fetches(rays)
+        cost.append((c["nodes"], c["tris"], c["rays_hit"]))
+        sc.close()
+    assert cost[0][2] == cost[1][2]                       # the same rays hit something
+    assert cost[1][0] < cost[0][0] and cost[1][1] < cost[0][1]

@@ -21,12 +21,13 @@ ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--rays", type=int, default=8 << 20)
 ap.add_argument("--out", default="full")
+ap.add_argument("--bvh", default="sah")
 ap.add_argument("configs", nargs="+")
 a = ap.parse_args()
 
 model, W, H = WORK[a.workload]
 mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "tolerant")
-bvh = rt.BVH(mesh, "fixed")
+bvh = rt.BVH(mesh, a.bvh)
 scene = rt.Scene(mesh, bvh, device=0)
 if W:
     rays = rt.primary_rays(W, H, rt.frame_camera(bvh.root_box, W, H))
