@@ -118,7 +118,7 @@ void FillArgs(const rt_scene *s, rt::KernelArgs &a)
   std::memset(&a, 0, sizeof a);
   if (s->quant) a.nodes = s->width == 4 ? s->d_nodesq4 : s->d_nodesq2;
   else a.nodes = s->width == 4 ? s->d_nodes4 : s->d_nodes2;
-  for (int k = 0; k < 3; ++k) { a.grid.lo[k] = s->flat.grid_lo[k]; a.grid.step[k] = s->flat.grid_step[k]; }
+  rt::SetQuantGrid(a.grid, s->flat.grid_lo, s->flat.grid_step);
   a.tris = s->d_tris;
   a.verts = s->d_verts;
   a.faces = s->d_faces;

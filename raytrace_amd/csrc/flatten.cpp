@@ -228,7 +228,7 @@ FetchCounts CountFetches(FlatScene const &fs, int width, bool quant, rt_ray_isec
                          size_t stride, uint32_t *per_ray)
 {
   QuantGrid grid;
-  for (int k = 0; k < 3; ++k) { grid.lo[k] = fs.grid_lo[k]; grid.step[k] = fs.grid_step[k]; }
+  SetQuantGrid(grid, fs.grid_lo, fs.grid_step);
   FetchCounts fc;
   if (stride == 0) stride = 1;
   std::vector<uint32_t> stack(static_cast<size_t>(std::max(fs.stack2, fs.stack4)) + 8);
@@ -345,7 +345,7 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
 {
   WaveModel m;
   QuantGrid grid;
-  for (int k = 0; k < 3; ++k) { grid.lo[k] = fs.grid_lo[k]; grid.step[k] = fs.grid_step[k]; }
+  SetQuantGrid(grid, fs.grid_lo, fs.grid_step);
   const uint32_t kDoneRef = 0xFFFFFFFFu;
   const uint32_t img_h = img_w ? static_cast<uint32_t>(nrays / img_w) : 0;
   const uint32_t tiles_x = img_w ? (img_w + 7) / 8 : 0;

@@ -170,18 +170,23 @@ __device__ __forceinline__ uint32_t Step4Q(const KernelArgs &p, const RayCtxQ &q
 
 __device__ __forceinline__ float Dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-// Ray record handled by `lane` of the wave that owns work unit `unit`; false if the lane falls off the ray set.
+// Where a wave's work unit sits: the first record of a linear run, or the pixel origin of an 8x8 tile.
+struct UnitPos {
+  uint32_t first;    // linear: index of lane 0's record
+  uint32_t x0, y0;   // image: pixel of lane 0
+};
+
+// Ray record handled by `lane` of the wave that owns the unit at `u`; false if the lane falls off the ray set.
 // Linear: the unit is 64 consecutive records.  Image: the unit is an 8x8 pixel tile (the reference launches 8x8
 // work-groups too, img_main.cpp:457-461), which keeps the 64 rays of a wave on neighbouring paths through the tree.
-__device__ __forceinline__ bool RayOfLane(const KernelArgs &p, uint32_t unit, uint32_t lane, uint32_t &idx)
+__device__ __forceinline__ bool RayOfLane(const KernelArgs &p, const UnitPos &u, uint32_t lane, uint32_t &idx)
 {
   if (p.img_w) {
-    const uint32_t tiles_x = (p.img_w + 7u) >> 3;
-    const uint32_t x = (unit % tiles_x) * 8u + (lane & 7u), y = (unit / tiles_x) * 8u + (lane >> 3);
+    const uint32_t x = u.x0 + (lane & 7u), y = u.y0 + (lane >> 3);
     idx = y * p.img_w + x;
     return x < p.img_w && y < p.img_h;
   }
-  idx = unit * 64u + lane;
+  idx = u.first + lane;
   return idx < p.n;
 }
 
@@ -202,8 +207,15 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
     // last ones alive) or, failing that, runs from the image centre out.
     uint32_t unit = base >> 6;
     if (p.order) unit = p.order[unit];
+    unit = __builtin_amdgcn_readfirstlane(unit);   // the same for every lane: keeps the index arithmetic scalar
+    UnitPos pos{unit * 64u, 0u, 0u};
+    if (p.img_w) {
+      const uint32_t tiles_x = (p.img_w + 7u) >> 3, ty = unit / tiles_x;
+      pos.x0 = (unit - ty * tiles_x) * 8u;
+      pos.y0 = ty * 8u;
+    }
     uint32_t idx;
-    const bool valid = RayOfLane(p, unit, lane, idx);
+    const bool valid = RayOfLane(p, pos, lane, idx);
     float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0, rec3 = rec0;   // this lane's output record
     uint32_t wave_cost = 0;
     uint32_t c_node = 0, c_tri = 0, c_leaf = 0, c_hit = 0;  // instrumented build: this lane's counts
@@ -307,8 +319,11 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
             const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
             const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
             nx = e1y * e2z - e1z * e2y; ny = e1z * e2x - e1x * e2z; nz = e1x * e2y - e1y * e2x;
-            const float len = sqrtf(nx * nx + ny * ny + nz * nz);
-            if (len > 0.f) { nx /= len; ny /= len; nz /= len; }
+            const float len2 = nx * nx + ny * ny + nz * nz;
+            if (len2 > 0.f) {   // one hardware reciprocal square root (1 ulp) instead of a square root and three divides
+              const float inv_len = __builtin_amdgcn_rsqf(len2);
+              nx *= inv_len; ny *= inv_len; nz *= inv_len;
+            }
           }
           out_n = make_float4(nx, ny, nz, 0.f);
           out_d = make_float4(dx, dy, dz, 0.f);
@@ -345,7 +360,7 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
         const uint32_t src = k * 16u + (lane >> 2), quarter = lane & 3u;
         const float4 v = tile[src * 4u + (quarter ^ ((src >> 2) & 3u))];
         uint32_t src_idx;
-        if (RayOfLane(p, unit, src, src_idx)) reinterpret_cast<float4 *>(p.hits + src_idx)[quarter] = v;
+        if (RayOfLane(p, pos, src, src_idx)) reinterpret_cast<float4 *>(p.hits + src_idx)[quarter] = v;
       }
     }
     if (p.unit_cost) {

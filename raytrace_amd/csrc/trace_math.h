@@ -90,7 +90,17 @@ RT_HD bool SlabTest(const RayCtx &r, float lox, float loy, float loz, float hix,
 struct QuantGrid {
   float lo[3];
   float step[3];
+  float inv_limit[3];   // bound on |1/d| per axis: keeps 2^23 * step * |1/d| finite for grids coarser than 1 unit per cell
 };
+
+RT_HD void SetQuantGrid(QuantGrid &g, const float lo[3], const float step[3])
+{
+  for (int k = 0; k < 3; ++k) {
+    g.lo[k] = lo[k];
+    g.step[k] = step[k];
+    g.inv_limit[k] = kInvClamp / fmaxf(step[k], 1.f);
+  }
+}
 
 constexpr uint32_t kBiasBits = 0x4B000000u;   // 2^23 as a float
 constexpr float kBias = 8388608.0f;
@@ -105,11 +115,9 @@ struct RayCtxQ {
   uint32_t fx, fy, fz;     // selector of the far plane's half
 };
 
-RT_HD void SetupRayQAxis(float o, float inv, bool neg, float pad, float glo, float step, float &a, float &bn, float &bf,
-                         uint32_t &seln, uint32_t &self)
+RT_HD void SetupRayQAxis(float o, float inv, bool neg, float pad, float glo, float step, float lim, float &a, float &bn,
+                         float &bf, uint32_t &seln, uint32_t &self)
 {
-  // keeps 2^23 * |a| finite for grids coarser than one unit per cell
-  const float lim = kInvClamp / fmaxf(step, 1.f);
   inv = fminf(fmaxf(inv, -lim), lim);
   const float p = neg ? -pad : pad;
   a = step * inv;
@@ -122,9 +130,9 @@ RT_HD void SetupRayQAxis(float o, float inv, bool neg, float pad, float glo, flo
 RT_HD void SetupRayQ(RayCtxQ &q, const RayCtx &r, const QuantGrid &g, float scale)
 {
   const float pad = kPadFactor * (fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz)) + scale);
-  SetupRayQAxis(r.ox, r.ix, r.sx, pad, g.lo[0], g.step[0], q.ax, q.bnx, q.bfx, q.nx, q.fx);
-  SetupRayQAxis(r.oy, r.iy, r.sy, pad, g.lo[1], g.step[1], q.ay, q.bny, q.bfy, q.ny, q.fy);
-  SetupRayQAxis(r.oz, r.iz, r.sz, pad, g.lo[2], g.step[2], q.az, q.bnz, q.bfz, q.nz, q.fz);
+  SetupRayQAxis(r.ox, r.ix, r.sx, pad, g.lo[0], g.step[0], g.inv_limit[0], q.ax, q.bnx, q.bfx, q.nx, q.fx);
+  SetupRayQAxis(r.oy, r.iy, r.sy, pad, g.lo[1], g.step[1], g.inv_limit[1], q.ay, q.bny, q.bfy, q.ny, q.fy);
+  SetupRayQAxis(r.oz, r.iz, r.sz, pad, g.lo[2], g.step[2], g.inv_limit[2], q.az, q.bnz, q.bfz, q.nz, q.fz);
 }
 
 // 2^23 + (the half of `word` that `sel` names), as a float.
