@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--block", type=int, default=0, help="workgroup threads: 64, 128 or 256 (0 = library default)")
     ap.add_argument("--image-hint", type=int, default=1, help="declare the ray array as a W-wide image (8x8 tiles per wave)")
     ap.add_argument("--waves-per-cu", type=int, default=-1, help="resident-wave cap per CU (-1 = library default)")
+    ap.add_argument("--raygen", default="table", choices=["table", "device"],
+                    help="table: rays are a RayIntersection array resident in HBM (the reference's interface); device: "
+                         "the same primary rays are generated inside the kernel (rt_trace_primary), no ray array is read")
     ap.add_argument("--feedback", type=int, default=1,
                     help="1: each launch starts its work units costliest-first, by the costs measured two launches earlier")
     return ap.parse_args()
@@ -183,6 +186,9 @@ def main():
                     q.wait()
             else:
                 dist.isend(hits16_d, dst=0).wait()
+        elif a.raygen == "device" and W:
+            scene.trace_primary(W, H, origin, hits_d.data_ptr() if full_out else None,
+                                None if full_out else hits_d.data_ptr(), stream)
         elif full_out:
             scene.intersect_async(rays_d.data_ptr(), n_local, hits_d.data_ptr(), None, stream)
         else:
@@ -231,7 +237,8 @@ def main():
         node_b = info["node4_bytes"] if width == 4 else info["node2_bytes"]
         n_node, n_tri = cnt["nodes"] / cnt["rays"], cnt["tris"] / cnt["rays"]
         out_b = 64 if (full_out and not (a.workload == "tiles4k" and world > 1)) else 16
-        bytes_per_ray = 64 + out_b + n_node * node_b + n_tri * info["tri_bytes"]
+        in_b = 0 if (a.raygen == "device" and W and a.workload not in ("tiles4k", "mirror5")) else 64
+        bytes_per_ray = in_b + out_b + n_node * node_b + n_tri * info["tri_bytes"]
         if a.workload == "mirror5":
             # reflection passes trace rays that exist only inside the kernel: their records are not counted, so
             # the figure below prices every pass at the streams alone (record in, record out, RGBA pixel)
@@ -244,8 +251,12 @@ def main():
             "node_records_per_ray": round(n_node, 3), "tri_records_per_ray": round(n_tri, 3),
             "node_records_per_ray_cpu_sample": round(cnt_cpu["nodes"] / max(1, cnt_cpu["rays"]), 3),
             "tri_records_per_ray_cpu_sample": round(cnt_cpu["tris"] / max(1, cnt_cpu["rays"]), 3),
-            "node_bytes": node_b, "tri_bytes": info["tri_bytes"], "ray_in_bytes": 64, "hit_out_bytes": out_b,
+            "node_bytes": node_b, "tri_bytes": info["tri_bytes"], "ray_in_bytes": in_b, "hit_out_bytes": out_b,
             "hit_fraction": round(cnt["rays_hit"] / cnt["rays"], 4),
+            # the two parts of the algorithmic figure on their own: the compulsory ray/hit streams (what HBM must
+            # move) and the traversal records (served by L1/L2; the L2 sustains roughly 17-19 TB/s of gathers)
+            "stream_GBs": round((in_b + out_b) * n_local / (dev_ms * 1e-3) / 1e9, 1),
+            "traversal_GBs": round((bytes_per_ray - in_b - out_b) * n_local / (dev_ms * 1e-3) / 1e9, 1),
         }
         # HBM-side bytes per launch from PMC counters: measured in separate rocprofv3 passes (tools/profile_gpu.sh),
         # committed next to the kernel-trace summary, looked up here by workload and output record
@@ -309,6 +320,7 @@ def main():
                        "name": a.workload, "rays_per_gpu": n_local, "rays_total": n_total, "triangles": len(mesh.faces),
                        "loader": "tolerant", "bvh": a.bvh, "bvh_width": width, "nodes": info["nodes4" if width == 4 else "nodes2"],
                        "hit_record": "64B RayIntersection" if out_b == 64 else "16B {id,t,u,v}",
+                       "rays": "RayIntersection table resident in HBM" if in_b else "generated in the kernel (rt_trace_primary)",
                        "dispatch_order": "costliest work unit first, from the costs measured two launches earlier" if a.feedback
                        else "image centre first",
                        "parallelism": f"{world} x frame-parallel" if a.workload != "tiles4k" else f"{world} x interleaved {a.tile}x{a.tile} tiles + RCCL gather"},

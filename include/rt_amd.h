@@ -141,6 +141,13 @@ int ray_scene_intersection(const void *rays, size_t n, const rt_scene *scene, vo
 int rt_intersect_async(const rt_scene *scene, const void *rays_dev, size_t n, void *hits_dev, void *hits16_dev,
                        void *stream);
 
+/* The same closest-hit query for the reference's primary-ray table (render_client/img_main.cpp:253-267) without
+ * the table: ray (i, j) of a width x height image is generated inside the kernel, bit-identical to what
+ * rt_primary_rays writes, so no 64-byte ray record is read.  Outputs as rt_intersect_async, record index
+ * i + j * width.  Enqueued on `stream` without waiting. */
+int rt_trace_primary(const rt_scene *scene, int width, int height, const float origin[3], void *hits_dev,
+                     void *hits16_dev, void *stream);
+
 /* The full `trace` kernel step (render_client/tracekernel.ck:192-414): op 0 applies the
  * camera matrix cam[16] (row-major, rows dotted with (x,y,z,w)) to origin (w=1) and
  * direction (w=0); op 1 reflects direction about the record's normal and nudges the

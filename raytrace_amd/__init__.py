@@ -90,6 +90,7 @@ def _load():
         "ray_scene_intersection": (i32, [vp, sz, vp, vp]),
         "rt_intersect_async": (i32, [vp, vp, sz, vp, vp, vp]),
         "rt_trace_pass": (i32, [vp, vp, vp, vp, sz, C.POINTER(C.c_float), u32, vp]),
+        "rt_trace_primary": (i32, [vp, i32, i32, C.POINTER(C.c_float), vp, vp, vp]),
         "rt_scene_count_fetches": (i32, [vp, vp, sz, sz, C.POINTER(u64), vp]),
         "rt_scene_count_fetches_device": (i32, [vp, vp, sz, C.POINTER(u64)]),
         "rt_scene_wave_timeline": (i32, [vp, vp, sz, vp, sz]),
@@ -258,6 +259,11 @@ class Scene:
     def intersect_async(self, rays_ptr, n, hits_ptr=None, hits16_ptr=None, stream=0):
         _check(lib.rt_intersect_async(self._h, _ptr(rays_ptr), n, _ptr(hits_ptr), _ptr(hits16_ptr),
                                       C.c_void_p(stream) if stream else None))
+
+    def trace_primary(self, width, height, origin, hits_ptr=None, hits16_ptr=None, stream=0):
+        o = (C.c_float * 3)(*[float(x) for x in origin])
+        _check(lib.rt_trace_primary(self._h, width, height, o, _ptr(hits_ptr), _ptr(hits16_ptr),
+                                    C.c_void_p(stream) if stream else None))
 
     def trace_pass(self, rays_in_ptr, rays_out_ptr, rgba_ptr, n, cam, op, stream=0):
         cam_arr = (C.c_float * 16)(*[float(x) for x in np.asarray(cam, dtype=np.float32).reshape(16)])

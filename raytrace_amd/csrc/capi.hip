@@ -186,10 +186,11 @@ int ResetFeedback(const rt_scene *s)
 // Enqueues one launch over at most 2^30 rays.
 int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStream_t stream)
 {
+  const uint32_t width_hint = mode == rt::kModePrimary ? a.img_w : static_cast<uint32_t>(s->image_width);
   a.img_w = a.img_h = 0;
   a.ntasks = (a.n + 63u) / 64u;
-  if (s->image_width > 0 && a.n % static_cast<uint32_t>(s->image_width) == 0) {
-    a.img_w = static_cast<uint32_t>(s->image_width);
+  if (width_hint > 0 && a.n % width_hint == 0) {
+    a.img_w = width_hint;
     a.img_h = a.n / a.img_w;
     a.ntasks = ((a.img_w + 7u) / 8u) * ((a.img_h + 7u) / 8u);
     if (s->centre_first) {
@@ -573,6 +574,27 @@ int rt_intersect_async(const rt_scene *s, const void *rays_dev, size_t n, void *
     if (rc != RT_OK) return rc;
   }
   return RT_OK;
+}
+
+int rt_trace_primary(const rt_scene *s, int width, int height, const float origin[3], void *hits_dev, void *hits16_dev,
+                     void *stream)
+{
+  if (!s) return Fail(RT_ERR_INVALID, "null scene");
+  if (s->device == RT_DEVICE_NONE) return Fail(RT_ERR_DEVICE, "scene was created without a device");
+  if (width <= 0 || height <= 0 || !origin) return Fail(RT_ERR_INVALID, "bad primary-ray arguments");
+  if (static_cast<uint64_t>(width) * static_cast<uint64_t>(height) >= kFeedbackMaxRays)
+    return Fail(RT_ERR_INVALID, "image too large for one launch");
+  if (!hits_dev && !hits16_dev) return Fail(RT_ERR_INVALID, "null hit buffer");
+  DeviceGuard guard(s->device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  rt::KernelArgs a;
+  FillArgs(s, a);
+  a.hits = static_cast<rt_ray_isect *>(hits_dev);
+  a.hits16 = static_cast<rt_hit16 *>(hits16_dev);
+  a.n = static_cast<uint32_t>(width) * static_cast<uint32_t>(height);
+  a.img_w = static_cast<uint32_t>(width);   // the generator needs pixel coordinates: always traced as an image
+  a.cam[0] = origin[0]; a.cam[1] = origin[1]; a.cam[2] = origin[2];
+  return Enqueue(s, a, rt::kModePrimary, false, static_cast<hipStream_t>(stream));
 }
 
 int ray_scene_intersection(const void *rays, size_t n, const rt_scene *scene, void *hits)

@@ -15,6 +15,7 @@ constexpr uint32_t kLeafBitDev = 0x80000000u;
 constexpr int kModeIntersect = 0;  // rays used as given (ray_scene_intersection)
 constexpr int kFbBuckets = 16;     // cost bins of the launch-to-launch feedback schedule
 constexpr int kModeTrace = 1;      // full `trace` step: camera / reflection setup + pixel
+constexpr int kModePrimary = 2;    // rays of the reference's primary table, generated in the kernel (no ray array)
 
 struct KernelArgs {
   const float4 *nodes;        // float boxes: 4 (two-wide) or 8 (four-wide) float4 per record;
@@ -44,7 +45,7 @@ struct KernelArgs {
   uint32_t img_h;
   uint32_t leaf_pct;          // switch from node steps to leaf steps once this percentage of busy lanes hold a leaf
   float scale;                // max |coordinate| of the scene box (slab padding)
-  float cam[16];
+  float cam[16];              // kModeTrace: camera matrix; kModePrimary: cam[0..2] = ray origin
   QuantGrid grid;             // quantized layouts only
 };
 

@@ -221,7 +221,21 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
     uint32_t c_node = 0, c_tri = 0, c_leaf = 0, c_hit = 0;  // instrumented build: this lane's counts
     if (valid) {
       const float4 *rp = reinterpret_cast<const float4 *>(p.rays + idx);
-      const float4 in_o = LoadF4(rp), in_d = LoadF4(rp + 1);
+      float4 in_o, in_d;
+      if (MODE == kModePrimary) {
+        // the reference's camera table, computed instead of read (render_client/img_main.cpp:253-267,
+        // core/raymath.cpp:6-15): eye = (W/2, H/2, -5W), direction = normalize((i, j, 0) - eye), the same float
+        // operations in the same order as the host generator, so the rays are bit-identical to its table
+        const float ex = p.img_w / 2.f, ey = p.img_h / 2.f, ez = static_cast<float>(-5 * static_cast<int>(p.img_w));
+        const float tx = static_cast<float>(pos.x0 + (lane & 7u)) - ex, ty = static_cast<float>(pos.y0 + (lane >> 3)) - ey,
+                    tz = 0.f - ez;
+        const float len = sqrtf(tx * tx + ty * ty + tz * tz);
+        in_o = make_float4(p.cam[0], p.cam[1], p.cam[2], 1.f);
+        in_d = make_float4(tx / len, ty / len, tz / len, 0.f);
+      } else {
+        in_o = LoadF4(rp);
+        in_d = LoadF4(rp + 1);
+      }
       float ox = in_o.x, oy = in_o.y, oz = in_o.z, dx = in_d.x, dy = in_d.y, dz = in_d.z;
       bool live = true;
       if (MODE == kModeTrace) {
@@ -502,6 +516,7 @@ hipError_t LaunchLayout(const KernelArgs &a, int mode, bool count, uint32_t grid
 {
   if (count) return LaunchOne<WIDTH, QUANT, kModeIntersect, true>(a, grid, block, lds, stream);
   if (mode == kModeTrace) return LaunchOne<WIDTH, QUANT, kModeTrace, false>(a, grid, block, lds, stream);
+  if (mode == kModePrimary) return LaunchOne<WIDTH, QUANT, kModePrimary, false>(a, grid, block, lds, stream);
   return LaunchOne<WIDTH, QUANT, kModeIntersect, false>(a, grid, block, lds, stream);
 }
 

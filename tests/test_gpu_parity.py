@@ -321,3 +321,30 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
             out = scene.intersect(shifted)
             assert np.array_equal(bits(out), bits(np.roll(base[:n], rep * 17, axis=0))), (n, rep)
     scene.close()
+
+
+@pytest.mark.parametrize("W,H", [(640, 360), (203, 97), (8, 8), (1, 1)])
+def test_rays_generated_in_the_kernel_equal_the_table(rt, gpu, W, H):
+    """rt_trace_primary computes ray (i, j) of the reference's camera table inside the kernel; its records
+    must be the bits that tracing the host-generated table gives, ragged image edges included."""
+    import torch
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "teapot.obj"), "reference")
+    bvh = rt.BVH(mesh, "sah")
+    scene = rt.Scene(mesh, bvh, device=gpu)
+    origin = rt.frame_camera(bvh.root_box, max(W, 16), max(H, 16))
+    table = scene.intersect(rt.primary_rays(W, H, origin))
+    for feedback in (0, 1):
+        scene.set_param("feedback", feedback)
+        for rep in range(3):
+            full = torch.zeros((W * H, 16), dtype=torch.float32, device="cuda")
+            compact = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
+            scene.trace_primary(W, H, origin, full.data_ptr(), compact.data_ptr())
+            torch.cuda.synchronize()
+            got = full.cpu().numpy()
+            assert np.array_equal(bits(got), bits(table)), (feedback, rep)
+            ids, t, u, v = rt.hit_fields(table)
+            c = compact.cpu().numpy()
+            assert np.array_equal(c[:, 0].view(np.uint32), ids) and np.array_equal(bits(c[:, 1]), bits(t))
+    with pytest.raises(rt.RtError):
+        scene.trace_primary(0, 4, origin, 1, None)
+    scene.close()

@@ -53,3 +53,12 @@ if "SQ_ACTIVE_INST_VALU" in m and "SQ_BUSY_CYCLES" in m:
     print(f"VALU active / SQ busy cycles: {m['SQ_ACTIVE_INST_VALU']/m['SQ_BUSY_CYCLES']:.4f}")
 if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m:
     print(f"VALU lane utilisation (thread cycles / (active cycles x 64)): {m['SQ_THREAD_CYCLES_VALU']/(m['SQ_ACTIVE_INST_VALU']*64):.4f}")
+
+if "SQ_ACTIVE_INST_VALU" in m and "SQ_BUSY_CYCLES" in m:
+    # SQ counters are summed over the 32 shader engines and count in units of four cycles; a shader engine has
+    # 8 CUs x 4 SIMDs, so 8 quad-cycles of VALU issue are on offer per SE cycle
+    print(f"VALU issue utilisation while busy (active quad-cycles / (busy cycles x 8)): {m['SQ_ACTIVE_INST_VALU']/(m['SQ_BUSY_CYCLES']*8):.3f}")
+if "SQ_WAVE_CYCLES" in m and "SQ_BUSY_CYCLES" in m:
+    print(f"mean resident waves per CU while busy (wave quad-cycles x 4 / busy cycles / 8 CUs): {m['SQ_WAVE_CYCLES']*4/m['SQ_BUSY_CYCLES']/8:.1f}")
+if "SQ_INSTS_VALU" in m and "SQ_WAVES" in m:
+    print(f"VALU / SALU / VMEM-read / LDS instructions per wave: {m['SQ_INSTS_VALU']/m['SQ_WAVES']:.0f} / {m.get('SQ_INSTS_SALU',0)/m['SQ_WAVES']:.0f} / {m.get('SQ_INSTS_VMEM_RD',0)/m['SQ_WAVES']:.0f} / {m.get('SQ_INSTS_LDS',0)/m['SQ_WAVES']:.0f}")
