@@ -181,3 +181,39 @@ def test_five_pass_bounce_chain_full_size(rt, oracle, gpu, model):
     assert hits_per_pass[0] > 0 and all(a >= b for a, b in zip(hits_per_pass, hits_per_pass[1:]))
     if model == "cube_mirror_test.obj":
         assert hits_per_pass[1] > 0      # the mirror slab really reflects onto the cube
+
+
+def test_headless_driver_frame_matches_the_library_path(rt, gpu, tmp_path):
+    """tools/rt_headless (the stand-in for the reference's windowed client, written against the C header only)
+    renders primary + one bounce and writes a BMP; the same frame composed here from rt_trace_pass layers with
+    the reference's blend (render_client/img_main.cpp:434,512-526) must give the same bytes."""
+    import subprocess
+    import torch
+    exe = os.path.join(os.path.dirname(MODELS.rstrip("/")), "..", "tools", "rt_headless")
+    exe = os.path.normpath(exe)
+    if not os.path.exists(exe):
+        pytest.fail(f"{exe} is missing: run make")
+    W, H = 160, 96
+    model = os.path.join(MODELS, "cube_mirror_test.obj")
+    out = str(tmp_path / "frame.bmp")
+    r = subprocess.run([exe, "--model", model, "--width", str(W), "--height", str(H), "--loader", "reference", "--bvh", "sah",
+                        "--bounces", "1", "--device", str(gpu), "--out", out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Triangles: 24" in r.stdout
+    data = open(out, "rb").read()
+    assert data[:2] == b"BM" and len(data) == 58 + W * H * 4
+    got = np.frombuffer(data[58:], np.uint8).reshape(H, W, 4)[::-1]          # rows are stored bottom-up
+
+    mesh = rt.Mesh.load_obj(model, "reference")
+    bvh = rt.BVH(mesh, "sah")
+    scene = rt.Scene(mesh, bvh, device=gpu)
+    rays = framed_primary(rt, bvh, W, H)
+    out0, rgba0 = run_pass(scene, rays, np.eye(4, dtype=f32), 0)
+    out1, rgba1 = run_pass(scene, out0, np.eye(4, dtype=f32), 1)
+    frame = rgba0.copy()
+    sa, da = rgba1[:, 3:4], frame[:, 3:4].copy()
+    frame = rgba1 * sa + frame * (f32(1) - da)
+    q = np.clip(frame * f32(255) + f32(0.5), 0, 255).astype(np.uint8).reshape(H, W, 4)
+    want = np.stack([q[..., 2], q[..., 1], q[..., 0], np.full((H, W), 255, np.uint8)], axis=-1)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1            # float blend order may differ in the last bit
+    assert (got[..., :3].sum(axis=-1) > 0).mean() > 0.02                      # the frame shows something

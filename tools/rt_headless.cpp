@@ -6,7 +6,7 @@
 // writes a BMP instead of presenting a window.
 //
 //   rt_headless [--model PATH] [--width W] [--height H] [--loader reference|tolerant]
-//               [--bvh reference|fixed] [--wide 2|4] [--bounces N] [--device D] [--out FILE.bmp]
+//               [--bvh reference|fixed|sah] [--wide 2|4] [--bounces N] [--device D] [--out FILE.bmp]
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -47,7 +47,10 @@ int main(int argc, char **argv)
     else if (a == "--width") W = std::atoi(next());
     else if (a == "--height") H = std::atoi(next());
     else if (a == "--loader") loader = std::string(next()) == "reference" ? RT_LOADER_REFERENCE : RT_LOADER_TOLERANT;
-    else if (a == "--bvh") bvhmode = std::string(next()) == "reference" ? RT_BVH_REFERENCE : RT_BVH_FIXED;
+    else if (a == "--bvh") {
+      const std::string m = next();
+      bvhmode = m == "reference" ? RT_BVH_REFERENCE : (m == "sah" ? RT_BVH_SAH : RT_BVH_FIXED);
+    }
     else if (a == "--wide") wide = std::atoi(next());
     else if (a == "--bounces") bounces = std::atoi(next());
     else if (a == "--device") device = std::atoi(next());
