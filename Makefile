@@ -39,8 +39,17 @@ tools/rt_headless: tools/rt_headless.cpp $(OUT) $(HDRS)
 oracle:
 	$(MAKE) -C oracle
 
+# The host half of the library (no GPU code) under AddressSanitizer + UndefinedBehaviorSanitizer.
+sanitize-host: $(BUILD)/host_selftest_san
+	ASAN_OPTIONS=verify_asan_link_order=0:detect_leaks=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 $(BUILD)/host_selftest_san assets/models
+
+$(BUILD)/host_selftest_san: tools/host_selftest.cpp $(foreach s,$(HOST_SRCS),$(CS)/$(s).cpp) $(HDRS)
+	@mkdir -p $(BUILD)
+	$(CXX) -std=c++17 -O1 -g -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude \
+	    -o $@ tools/host_selftest.cpp $(foreach s,$(HOST_SRCS),$(CS)/$(s).cpp) -lpthread
+
 clean:
 	rm -rf $(BUILD) $(OUT) tools/rt_headless
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean sanitize-host

@@ -133,3 +133,16 @@ def test_bmp_writer_layout(rt, tmp_path):
     q = str(tmp_path / "x.pfm")
     rt.write_pfm(q, np.ones((H, W, 4), np.float32))
     assert open(q, "rb").read().startswith(b"PF\n5 3\n-1.0\n")
+
+
+def test_host_code_is_clean_under_address_and_ub_sanitizers():
+    """Loader, the three BVH builders, re-flattening, fetch counting, ray generators and image writers, driven by
+    tools/host_selftest.cpp in a build with -fsanitize=address,undefined (`make sanitize-host`)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("no host toolchain")
+    r = subprocess.run(["make", "sanitize-host"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "host_selftest: 0 failure(s)" in r.stdout
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
