@@ -95,7 +95,6 @@ struct rt_scene {
   mutable hipStream_t side = nullptr;                       // the order-building kernel runs here, beside the next trace
   mutable hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_sort[2] = {nullptr, nullptr};
   int waves_per_cu = 0;          // optional resident-wave cap per CU, held through the LDS stack size (0 = none)
-  int wide_cost = 0;             // feedback: units at least this costly (wave iterations) are traced four-wide; 0 = none
   int leaf_pct = 50;             // node/leaf step scheduling threshold (percent of busy lanes parked at a leaf)
   int extra_stack = 0;           // diagnostic: extra LDS stack entries per lane (lowers occupancy)
   int image_width = 0;           // hint: ray arrays are row-major images of this width (0 = unstructured)
@@ -236,10 +235,6 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     if (s->fb_sorted[fb_slot]) {
       RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[fb_slot], 0));
       a.order = s->d_fb_order[fb_slot];
-      if (s->width == 2 && s->quant && s->wide_cost > 0) {
-        a.nodes_wide = s->d_nodesq4;
-        a.stack_entries = std::max(a.stack_entries, static_cast<uint32_t>(s->flat.stack4 + s->extra_stack));
-      }
     }
     a.unit_cost = s->d_fb_cost[fb_slot];
   }
@@ -260,8 +255,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
   if (fb_slot >= 0) {
     RT_HIP(hipEventRecord(s->ev_main[fb_slot], stream));
     RT_HIP(hipStreamWaitEvent(s->side, s->ev_main[fb_slot], 0));
-    RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_order[fb_slot],
-                                (s->width == 2 && s->quant) ? static_cast<uint32_t>(s->wide_cost) : 0u, s->side));
+    RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_order[fb_slot], s->side));
     RT_HIP(hipEventRecord(s->ev_sort[fb_slot], s->side));
     s->fb_sorted[fb_slot] = true;
     s->fb_launch++;
@@ -537,14 +531,6 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "waves_per_cu") {
     if (value < 0 || value > 64) return Fail(RT_ERR_INVALID, "waves_per_cu must be in 0..64");
     s->waves_per_cu = value;
-  } else if (k == "wide_cost") {
-    if (value < 0) return Fail(RT_ERR_INVALID, "wide_cost must be >= 0");
-    s->wide_cost = value;
-    if (s->device != RT_DEVICE_NONE) {
-      DeviceGuard guard(s->device);
-      int rc = ResetFeedback(s);
-      if (rc != RT_OK) return rc;
-    }
   } else if (k == "centre_first") {
     s->centre_first = value != 0;
   } else if (k == "leaf_pct") {

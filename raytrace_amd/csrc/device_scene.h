@@ -15,13 +15,11 @@ constexpr uint32_t kLeafBitDev = 0x80000000u;
 constexpr int kModeIntersect = 0;  // rays used as given (ray_scene_intersection)
 constexpr int kFbBuckets = 16;     // cost bins of the launch-to-launch feedback schedule
 constexpr int kModeTrace = 1;      // full `trace` step: camera / reflection setup + pixel
-constexpr uint32_t kOrderWideBit = 0x80000000u;   // dispatch-order entry: trace this unit on the four-wide records
 constexpr int kModePrimary = 2;    // rays of the reference's primary table, generated in the kernel (no ray array)
 
 struct KernelArgs {
   const float4 *nodes;        // float boxes: 4 (two-wide) or 8 (four-wide) float4 per record;
                               // quantized boxes: one 16-byte child per float4 slot, 2 or 4 per record
-  const float4 *nodes_wide;   // nullable: quantized four-wide records for the units an order flags (two-wide launches)
   const float4 *tris;         // 3 float4 per record
   const rt_ray_isect *rays;
   rt_ray_isect *hits;         // nullable
@@ -56,9 +54,7 @@ hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode
 // order[k] = k-th unit to start, costliest bin first, index order within a bin (one 512-thread workgroup).
 // unit_cost must hold 512 * BuildOrderKeysPerThread(nunits) readable entries.
 uint32_t BuildOrderKeysPerThread(uint32_t nunits);
-// Units whose cost is at least `wide_cost` (0 = none) get kOrderWideBit.
-hipError_t LaunchBuildOrder(const uint32_t *unit_cost, uint32_t nunits, uint32_t *order, uint32_t wide_cost,
-                            hipStream_t stream);
+hipError_t LaunchBuildOrder(const uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream);
 hipError_t LaunchTriBatch(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv,
                           hipStream_t stream);
 

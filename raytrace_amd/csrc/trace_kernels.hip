@@ -116,10 +116,10 @@ __device__ __forceinline__ uint32_t Step4(const KernelArgs &p, const RayCtx &r, 
 }
 
 // Quantized records: WIDTH children of 16 bytes each {x, y, z axis words, reference}.
-__device__ __forceinline__ uint32_t Step2Q(const float4 *nodes, const RayCtxQ &q, uint32_t cur, float tbest,
+__device__ __forceinline__ uint32_t Step2Q(const KernelArgs &p, const RayCtxQ &q, uint32_t cur, float tbest,
                                            uint32_t *stk, uint32_t &sp)
 {
-  const uint4 *np = reinterpret_cast<const uint4 *>(nodes) + static_cast<size_t>(cur) * 2u;
+  const uint4 *np = reinterpret_cast<const uint4 *>(p.nodes) + static_cast<size_t>(cur) * 2u;
   const uint4 c0 = np[0], c1 = np[1];
   float t0, t1;
   const bool h0 = SlabTestQ(q, c0.x, c0.y, c0.z, tbest, t0);
@@ -136,10 +136,10 @@ __device__ __forceinline__ uint32_t Step2Q(const float4 *nodes, const RayCtxQ &q
   return stk[--sp * 64u];
 }
 
-__device__ __forceinline__ uint32_t Step4Q(const float4 *nodes, const RayCtxQ &q, uint32_t cur, float tbest,
+__device__ __forceinline__ uint32_t Step4Q(const KernelArgs &p, const RayCtxQ &q, uint32_t cur, float tbest,
                                            uint32_t *stk, uint32_t &sp)
 {
-  const uint4 *np = reinterpret_cast<const uint4 *>(nodes) + static_cast<size_t>(cur) * 4u;
+  const uint4 *np = reinterpret_cast<const uint4 *>(p.nodes) + static_cast<size_t>(cur) * 4u;
   const uint4 c0 = np[0], c1 = np[1], c2 = np[2], c3 = np[3];
   float t0, t1, t2, t3;
   const bool h0 = SlabTestQ(q, c0.x, c0.y, c0.z, tbest, t0);
@@ -208,11 +208,6 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
     uint32_t unit = base >> 6;
     if (p.order) unit = p.order[unit];
     unit = __builtin_amdgcn_readfirstlane(unit);   // the same for every lane: keeps the index arithmetic scalar
-    // A cost-sorted order flags the units whose rays are the longest: their waves walk the four-wide records,
-    // which halves the chain of dependent fetches that the whole launch ends up waiting for (at more arithmetic
-    // per step, which is why the other waves do not).
-    const bool wide = QUANT && WIDTH == 2 && !COUNT && p.nodes_wide && (unit & kOrderWideBit);
-    unit &= ~kOrderWideBit;
     UnitPos pos{unit * 64u, 0u, 0u};
     if (p.img_w) {
       const uint32_t tiles_x = (p.img_w + 7u) >> 3, ty = unit / tiles_x;
@@ -288,8 +283,7 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
           if (inner) {
             if (COUNT) nnode++;
             if (QUANT)
-              cur = (WIDTH == 4 || wide) ? Step4Q(WIDTH == 4 ? p.nodes : p.nodes_wide, rq, cur, best.t, stk, sp)
-                                         : Step2Q(p.nodes, rq, cur, best.t, stk, sp);
+              cur = (WIDTH == 4) ? Step4Q(p, rq, cur, best.t, stk, sp) : Step2Q(p, rq, cur, best.t, stk, sp);
             else
               cur = (WIDTH == 4) ? Step4(p, r, cur, best.t, stk, sp) : Step2(p, r, cur, best.t, stk, sp);
           }
@@ -423,8 +417,7 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
 // handful of memory round trips instead of one per key.  unit_cost must be readable up to 512*per entries.
 __device__ __forceinline__ uint32_t CostBin(uint32_t cost) { return min(cost >> 4, static_cast<uint32_t>(kFbBuckets - 1)); }
 
-__global__ void __launch_bounds__(512) BuildOrderKernel(const uint32_t *unit_cost, uint32_t n, uint32_t per, uint32_t *order,
-                                                        uint32_t wide_cost)
+__global__ void __launch_bounds__(512) BuildOrderKernel(const uint32_t *unit_cost, uint32_t n, uint32_t per, uint32_t *order)
 {
   __shared__ uint32_t table[kFbBuckets * 512];   // [bin, costliest first][thread]: counts, then next free position
   __shared__ uint32_t partial[8];
@@ -487,7 +480,7 @@ __global__ void __launch_bounds__(512) BuildOrderKernel(const uint32_t *unit_cos
           uint32_t *cell = &table[(kFbBuckets - 1 - CostBin(v[e])) * 512 + t];
           const uint32_t pos = *cell;
           *cell = pos + 1u;
-          order[pos] = i | (v[e] >= wide_cost ? kOrderWideBit : 0u);
+          order[pos] = i;
         }
       }
     }
@@ -542,12 +535,11 @@ hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode
 
 uint32_t BuildOrderKeysPerThread(uint32_t nunits) { return ((nunits + 511u) / 512u + 31u) / 32u * 32u; }
 
-hipError_t LaunchBuildOrder(const uint32_t *unit_cost, uint32_t nunits, uint32_t *order, uint32_t wide_cost,
-                            hipStream_t stream)
+hipError_t LaunchBuildOrder(const uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream)
 {
   (void)hipGetLastError();
   hipLaunchKernelGGL(BuildOrderKernel, dim3(1), dim3(512), 0, stream, unit_cost, nunits, BuildOrderKeysPerThread(nunits),
-                     order, wide_cost ? wide_cost : 0xFFFFFFFFu);
+                     order);
   return hipGetLastError();
 }
 
