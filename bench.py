@@ -76,6 +76,11 @@ def parse():
     ap.add_argument("--raygen", default="table", choices=["table", "device"],
                     help="table: rays are a RayIntersection array resident in HBM (the reference's interface); device: "
                          "the same primary rays are generated inside the kernel (rt_trace_primary), no ray array is read")
+    ap.add_argument("--frames", type=int, default=4,
+                    help="image workloads: distinct camera positions (ray tables, all resident in HBM) the steps cycle "
+                         "through, so that no step repeats the previous step's rays")
+    ap.add_argument("--feedback-radius", type=int, default=-1, help="-1 = library default")
+    ap.add_argument("--feedback-share", type=int, default=-1, help="-1 = library default")
     ap.add_argument("--feedback", type=int, default=1,
                     help="1: each launch starts its work units costliest-first, by the costs measured two launches earlier")
     return ap.parse_args()
@@ -128,6 +133,10 @@ def main():
     if W and a.workload != "tiles4k" and a.image_hint:
         scene.set_param("image_width", W)
     scene.set_param("feedback", a.feedback)
+    if a.feedback_radius >= 0:
+        scene.set_param("feedback_radius", a.feedback_radius)
+    if a.feedback_share >= 0:
+        scene.set_param("feedback_share", a.feedback_share)
     if a.waves_per_cu >= 0:
         scene.set_param("waves_per_cu", a.waves_per_cu)
     info = scene.info()
@@ -151,6 +160,18 @@ def main():
             own = None
         n_local = len(rays_h)
     rays_d = torch.from_numpy(rays_h).cuda()
+    # A render loop never traces the same rays twice: frame k of the timed loop looks from origin_k, a camera
+    # that drifts sideways by 0.2 % of the scene width per frame and returns after `frames` frames.
+    frames = max(1, a.frames) if a.workload in ("dragon1080", "bunny1080", "dragon4k") else 1
+    origins, tables = [], [rays_d]
+    if a.workload != "ao":
+        for k in range(frames):
+            o = origin.copy()
+            o[0] += k * 0.002 * float(box[1, 0] - box[0, 0])
+            origins.append(o)
+            if k > 0 and a.raygen == "table":
+                tables.append(torch.from_numpy(rt.primary_rays(W, H, o)).cuda())
+    step_no = [0]
     full_out = a.out == "full" or a.workload == "mirror5"
     hits_d = torch.empty((n_local, 16 if full_out else 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -169,6 +190,9 @@ def main():
         cam = np.eye(4, dtype=np.float32)
 
     def step():
+        k = step_no[0] % frames
+        step_no[0] += 1
+        rays_k = tables[k] if k < len(tables) else rays_d
         if a.workload == "mirror5":
             # pass 0 reads the primary table; passes 1..4 reflect the previous pass's records (ping-pong)
             scene.trace_pass(rays_d.data_ptr(), hits_d.data_ptr(), rgba_d.data_ptr(), n_local, cam, 0, stream)
@@ -187,12 +211,12 @@ def main():
             else:
                 dist.isend(hits16_d, dst=0).wait()
         elif a.raygen == "device" and W:
-            scene.trace_primary(W, H, origin, hits_d.data_ptr() if full_out else None,
+            scene.trace_primary(W, H, origins[k], hits_d.data_ptr() if full_out else None,
                                 None if full_out else hits_d.data_ptr(), stream)
         elif full_out:
-            scene.intersect_async(rays_d.data_ptr(), n_local, hits_d.data_ptr(), None, stream)
+            scene.intersect_async(rays_k.data_ptr(), n_local, hits_d.data_ptr(), None, stream)
         else:
-            scene.intersect_async(rays_d.data_ptr(), n_local, None, hits_d.data_ptr(), stream)
+            scene.intersect_async(rays_k.data_ptr(), n_local, None, hits_d.data_ptr(), stream)
 
     for _ in range(a.warmup):
         step()
@@ -232,6 +256,9 @@ def main():
         if a.workload == "mirror5":
             scene.set_param("feedback", 0)   # the counting launch below is a primary pass only
         cnt = scene.count_fetches_device(rays_d.data_ptr(), n_local)
+        for extra in tables[1:]:   # records fetched: the mean over the frames the loop cycles through
+            more = scene.count_fetches_device(extra.data_ptr(), n_local)
+            cnt = {key: cnt[key] + more[key] for key in cnt}
         stride = max(1, n_local // 8192)
         cnt_cpu = scene.count_fetches(rays_h, stride)
         node_b = info["node4_bytes"] if width == 4 else info["node2_bytes"]
@@ -287,6 +314,9 @@ def main():
             centroid = {"bvh": "fixed", "ms_per_step": round(cms, 4), "value": round(n_local / (cms * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
             scene_c.close()
 
+        step_no[0] = 0
+        step()                      # leaves frame 0's hits in hits_d for the spot check below
+        torch.cuda.synchronize()
         cpu = None
         if world == 1 and not a.no_cpu_baseline and a.workload != "mirror5":
             import oracle  # the CPU checker, used here only as the timed baseline
@@ -320,6 +350,7 @@ def main():
                        "name": a.workload, "rays_per_gpu": n_local, "rays_total": n_total, "triangles": len(mesh.faces),
                        "loader": "tolerant", "bvh": a.bvh, "bvh_width": width, "nodes": info["nodes4" if width == 4 else "nodes2"],
                        "hit_record": "64B RayIntersection" if out_b == 64 else "16B {id,t,u,v}",
+                       "frames": frames,
                        "rays": "RayIntersection table resident in HBM" if in_b else "generated in the kernel (rt_trace_primary)",
                        "dispatch_order": "costliest work unit first, from the costs measured two launches earlier" if a.feedback
                        else "image centre first",

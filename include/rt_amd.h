@@ -114,6 +114,10 @@ int rt_scene_info(const rt_scene *s, uint64_t info[8]);
  *                    kernel on a library-owned side stream turns that into a costliest-first dispatch order,
  *                    which the launch after next of the same shape (ray count, image width) on this scene uses.
  *                    A schedule only: every ray is traced on every launch.  Any change of shape starts over.
+ *   "feedback_radius" 0..3, "feedback_share" 0..128 (with "feedback"): a unit's measured cost also counts, scaled
+ *                    by share/128, for the units within `radius` of it (tiles in both image directions), so
+ *                    that the order still starts the right tiles first when the camera moved between the
+ *                    launches.  Defaults 1 and 96; 0 and anything = exact per-unit costs, best for repeated rays.
  *   "leaf_pct"       1..100: a wave switches from node steps to leaf steps once this share of its busy lanes
  *                    holds a leaf; 100 = descend until every lane does.
  *   "block_threads"  64, 128 or 256.

@@ -95,6 +95,8 @@ struct rt_scene {
   mutable hipStream_t side = nullptr;                       // the order-building kernel runs here, beside the next trace
   mutable hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_sort[2] = {nullptr, nullptr};
   int waves_per_cu = 0;          // optional resident-wave cap per CU, held through the LDS stack size (0 = none)
+  int feedback_share = 96;       // ... scaled by this many 128ths
+  int feedback_radius = 1;       // a unit's measured cost also counts for its neighbours this many units away
   int leaf_pct = 50;             // node/leaf step scheduling threshold (percent of busy lanes parked at a leaf)
   int extra_stack = 0;           // diagnostic: extra LDS stack entries per lane (lowers occupancy)
   int image_width = 0;           // hint: ray arrays are row-major images of this width (0 = unstructured)
@@ -237,6 +239,8 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
       a.order = s->d_fb_order[fb_slot];
     }
     a.unit_cost = s->d_fb_cost[fb_slot];
+    a.cost_radius = static_cast<uint32_t>(s->feedback_radius);
+    a.cost_share = static_cast<uint32_t>(s->feedback_share);
   }
   if (s->feedback == 1 && count && s->fb_launch >= 1u && s->fb_ntasks == a.ntasks && s->fb_n == a.n && s->fb_img_w == a.img_w) {
     // instrumented launch: follow the newest cost-sorted order, read-only
@@ -531,6 +535,12 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "waves_per_cu") {
     if (value < 0 || value > 64) return Fail(RT_ERR_INVALID, "waves_per_cu must be in 0..64");
     s->waves_per_cu = value;
+  } else if (k == "feedback_share") {
+    if (value < 0 || value > 128) return Fail(RT_ERR_INVALID, "feedback_share must be in 0..128");
+    s->feedback_share = value;
+  } else if (k == "feedback_radius") {
+    if (value < 0 || value > 3) return Fail(RT_ERR_INVALID, "feedback_radius must be in 0..3");
+    s->feedback_radius = value;
   } else if (k == "centre_first") {
     s->centre_first = value != 0;
   } else if (k == "leaf_pct") {

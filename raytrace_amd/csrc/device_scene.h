@@ -37,6 +37,8 @@ struct KernelArgs {
   unsigned long long *timeline;  // instrumented build only, nullable: per wave {start, end (100 MHz ticks), hw id, xcc id}
   uint32_t n;
   uint32_t ntasks;            // wave-sized work items: ceil(n/64), or the number of 8x8 tiles
+  uint32_t cost_radius;       // a unit's cost is also recorded for its neighbours within this many units (<= 3)
+  uint32_t cost_share;        // ... scaled by this many 128ths
   uint32_t nnormals;
   uint32_t nmats;
   uint32_t stack_entries;     // LDS stack entries per lane
@@ -52,9 +54,9 @@ struct KernelArgs {
 hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool count, uint32_t grid,
                             uint32_t block, hipStream_t stream);
 // order[k] = k-th unit to start, costliest bin first, index order within a bin (one 512-thread workgroup).
-// unit_cost must hold 512 * BuildOrderKeysPerThread(nunits) readable entries.
+// unit_cost must hold 512 * BuildOrderKeysPerThread(nunits) entries; it is zeroed after being read.
 uint32_t BuildOrderKeysPerThread(uint32_t nunits);
-hipError_t LaunchBuildOrder(const uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream);
+hipError_t LaunchBuildOrder(uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream);
 hipError_t LaunchTriBatch(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv,
                           hipStream_t stream);
 

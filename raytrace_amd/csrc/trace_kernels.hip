@@ -378,8 +378,23 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
       }
     }
     if (p.unit_cost) {
+      // The cost is recorded for the unit and, scaled down by cost_share/128, for its neighbourhood (maximum
+      // wins; the buffer is zero before the launch): between two frames of a moving camera the expensive places
+      // of the image shift by a tile or two, and the order built from these numbers has to start THOSE tiles
+      // early as well, while ordinary tiles keep their own number.  One atomic instruction per wave: lane l
+      // handles neighbour l of the (2R+1)^2 window.
       const uint32_t cost = __builtin_amdgcn_readfirstlane(wave_cost);   // lane 0 always owns a ray
-      if (lane == 0) p.unit_cost[unit] = cost;
+      const uint32_t side = 2u * p.cost_radius + 1u;
+      if (p.img_w) {
+        const uint32_t tiles_x = (p.img_w + 7u) >> 3, tiles_y = (p.img_h + 7u) >> 3;
+        const uint32_t nx = (pos.x0 >> 3) + lane % side - p.cost_radius, ny = (pos.y0 >> 3) + lane / side - p.cost_radius;
+        const bool self = nx == (pos.x0 >> 3) && ny == (pos.y0 >> 3);
+        if (lane < side * side && nx < tiles_x && ny < tiles_y)
+          atomicMax(p.unit_cost + ny * tiles_x + nx, self ? cost : cost * p.cost_share / 128u);
+      } else {
+        const uint32_t nu = unit + lane - p.cost_radius;
+        if (lane < side && nu < p.ntasks) atomicMax(p.unit_cost + nu, nu == unit ? cost : cost * p.cost_share / 128u);
+      }
     }
     if (COUNT) {
       // one atomic per counter per wave, so the instrumented launch keeps the real launch's timing shape
@@ -414,15 +429,16 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
 // Counting sort of work units by cost bin (cost / 16, capped), costliest bin first, ascending unit index inside
 // a bin so neighbouring units stay neighbours.  One workgroup of 512 threads; thread t owns the contiguous run
 // [t*per, (t+1)*per) and reads it 32 keys at a time as eight independent 16-byte loads, so each pass costs a
-// handful of memory round trips instead of one per key.  unit_cost must be readable up to 512*per entries.
+// handful of memory round trips instead of one per key.  unit_cost must be readable and writable up to 512*per
+// entries and is left all zero.
 __device__ __forceinline__ uint32_t CostBin(uint32_t cost) { return min(cost >> 4, static_cast<uint32_t>(kFbBuckets - 1)); }
 
-__global__ void __launch_bounds__(512) BuildOrderKernel(const uint32_t *unit_cost, uint32_t n, uint32_t per, uint32_t *order)
+__global__ void __launch_bounds__(512) BuildOrderKernel(uint32_t *unit_cost, uint32_t n, uint32_t per, uint32_t *order)
 {
   __shared__ uint32_t table[kFbBuckets * 512];   // [bin, costliest first][thread]: counts, then next free position
   __shared__ uint32_t partial[8];
   const uint32_t t = threadIdx.x, lo = t * per;
-  const uint4 *keys4 = reinterpret_cast<const uint4 *>(unit_cost + lo);   // per is a multiple of 32
+  uint4 *keys4 = reinterpret_cast<uint4 *>(unit_cost + lo);   // per is a multiple of 32
 #pragma unroll
   for (int b = 0; b < kFbBuckets; ++b) table[b * 512 + t] = 0;
   // no barrier needed yet: every thread only touches its own column of the table in this pass
@@ -469,7 +485,10 @@ __global__ void __launch_bounds__(512) BuildOrderKernel(const uint32_t *unit_cos
   for (uint32_t c = 0; c < per; c += 32u) {
     uint4 k[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) k[j] = keys4[c / 4u + j];
+    for (int j = 0; j < 8; ++j) {
+      k[j] = keys4[c / 4u + j];
+      keys4[c / 4u + j] = make_uint4(0u, 0u, 0u, 0u);   // the next launch that records into this buffer takes maxima
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t v[4] = {k[j].x, k[j].y, k[j].z, k[j].w};
@@ -535,7 +554,7 @@ hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode
 
 uint32_t BuildOrderKeysPerThread(uint32_t nunits) { return ((nunits + 511u) / 512u + 31u) / 32u * 32u; }
 
-hipError_t LaunchBuildOrder(const uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream)
+hipError_t LaunchBuildOrder(uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream)
 {
   (void)hipGetLastError();
   hipLaunchKernelGGL(BuildOrderKernel, dim3(1), dim3(512), 0, stream, unit_cost, nunits, BuildOrderKeysPerThread(nunits),
