@@ -97,7 +97,6 @@ struct rt_scene {
   int waves_per_cu = 0;          // optional resident-wave cap per CU, held through the LDS stack size (0 = none)
   int feedback_share = 96;       // ... scaled by this many 128ths
   int feedback_radius = 1;       // a unit's measured cost also counts for its neighbours this many units away
-  int prefetch = 1;              // two-wide quantized records: prefetch both children's lines while the boxes are tested
   int leaf_pct = 50;             // node/leaf step scheduling threshold (percent of busy lanes parked at a leaf)
   int extra_stack = 0;           // diagnostic: extra LDS stack entries per lane (lowers occupancy)
   int image_width = 0;           // hint: ray arrays are row-major images of this width (0 = unstructured)
@@ -132,7 +131,6 @@ void FillArgs(const rt_scene *s, rt::KernelArgs &a)
   // at least 16 entries per lane: the output stage exchanges the wave's 64 x 64-byte records through the stack
   a.stack_entries = static_cast<uint32_t>(std::max(16, (s->width == 4 ? s->flat.stack4 : s->flat.stack2) + s->extra_stack));
   a.scale = s->flat.scale;
-  a.stack_entries += 2;   // two scratch rows per wave: destinations of the child-record prefetches
   a.leaf_pct = static_cast<uint32_t>(s->leaf_pct);
   a.stats = s->d_stats;
 }
@@ -543,8 +541,6 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "feedback_radius") {
     if (value < 0 || value > 3) return Fail(RT_ERR_INVALID, "feedback_radius must be in 0..3");
     s->feedback_radius = value;
-  } else if (k == "prefetch") {
-    s->prefetch = value != 0;
   } else if (k == "centre_first") {
     s->centre_first = value != 0;
   } else if (k == "leaf_pct") {

@@ -39,7 +39,6 @@ struct KernelArgs {
   uint32_t ntasks;            // wave-sized work items: ceil(n/64), or the number of 8x8 tiles
   uint32_t cost_radius;       // a unit's cost is also recorded for its neighbours within this many units (<= 3)
   uint32_t cost_share;        // ... scaled by this many 128ths
-  uint32_t prefetch;          // 1: two extra LDS rows per wave exist and child records are prefetched through them
   uint32_t nnormals;
   uint32_t nmats;
   uint32_t stack_entries;     // LDS stack entries per lane

@@ -116,26 +116,11 @@ __device__ __forceinline__ uint32_t Step4(const KernelArgs &p, const RayCtx &r, 
 }
 
 // Quantized records: WIDTH children of 16 bytes each {x, y, z axis words, reference}.
-// Starts the fetch of the line that holds record `ref` of the node array (inner reference) or the first triangle
-// of the leaf (leaf reference) without holding a register for it: a one-dword load whose destination is a
-// scratch row of the wave's LDS area.  By the time the traversal asks for the record, a step later, it is in the
-// CU's L1 or on its way there.
-__device__ __forceinline__ void Prefetch(const KernelArgs &p, uint32_t ref, uint32_t *scratch_row)
-{
-  typedef const void __attribute__((address_space(1))) *GlobalPtr;
-  typedef void __attribute__((address_space(3))) *LdsPtr;
-  const char *addr = (ref & kLeafBitDev) ? reinterpret_cast<const char *>(p.tris) + static_cast<size_t>((ref & 0x7FFFFFFFu) >> 3) * 48u
-                                         : reinterpret_cast<const char *>(p.nodes) + static_cast<size_t>(ref) * 32u;
-  __builtin_amdgcn_global_load_lds((GlobalPtr)addr, (LdsPtr)scratch_row, 4, 0, 0);
-}
-
 __device__ __forceinline__ uint32_t Step2Q(const KernelArgs &p, const RayCtxQ &q, uint32_t cur, float tbest,
-                                           uint32_t *stk, uint32_t &sp, uint32_t *scratch)
+                                           uint32_t *stk, uint32_t &sp)
 {
   const uint4 *np = reinterpret_cast<const uint4 *>(p.nodes) + static_cast<size_t>(cur) * 2u;
   const uint4 c0 = np[0], c1 = np[1];
-  Prefetch(p, c0.w, scratch);
-  Prefetch(p, c1.w, scratch + 64);
   float t0, t1;
   const bool h0 = SlabTestQ(q, c0.x, c0.y, c0.z, tbest, t0);
   const bool h1 = SlabTestQ(q, c1.x, c1.y, c1.z, tbest, t1);
@@ -298,7 +283,7 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
           if (inner) {
             if (COUNT) nnode++;
             if (QUANT)
-              cur = (WIDTH == 4) ? Step4Q(p, rq, cur, best.t, stk, sp) : Step2Q(p, rq, cur, best.t, stk, sp, lds_stack + (wave * p.stack_entries + p.stack_entries - 2u) * 64u);
+              cur = (WIDTH == 4) ? Step4Q(p, rq, cur, best.t, stk, sp) : Step2Q(p, rq, cur, best.t, stk, sp);
             else
               cur = (WIDTH == 4) ? Step4(p, r, cur, best.t, stk, sp) : Step2(p, r, cur, best.t, stk, sp);
           }
