@@ -6,7 +6,7 @@ rt_intersect_async) over one batch of rays that is already resident in HBM.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] ...
 
-Workloads (BASELINE.json configs):
+Workloads:
   dragon1080   dragon.obj 1920x1080 primary rays           (default; the headline metric)
   bunny1080    bunny.obj 1920x1080 primary rays
   dragon4k     dragon.obj 3840x2160 primary rays

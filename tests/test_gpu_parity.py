@@ -121,7 +121,7 @@ def test_incoherent_rays_match_oracle(rt, oracle, gpu):
 
 
 def test_full_size_properties(rt, gpu):
-    """BASELINE sizes, checked through size-independent properties: the record layouts and both
+    """Full benchmark sizes, checked through size-independent properties: the record layouts and both
     ray-to-lane mappings agree on every one of the 2 073 600 / 8 294 400 rays, hit records are
     self-consistent (origin + t*dir lands on the reported hit point, barycentrics inside the
     triangle), and tracing the hit set again is idempotent."""
