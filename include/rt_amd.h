@@ -38,6 +38,8 @@ int rt_device_count(void);
  * render_client/img_main.cpp:240 does, so material 0 is the sky. */
 #define RT_LOADER_REFERENCE 0u  /* the reference tokenizer: repeated spaces produce empty tokens */
 #define RT_LOADER_TOLERANT  1u  /* empty tokens dropped; otherwise identical */
+#define RT_LOADER_EXTENDED  2u  /* tolerant, and quads / n-gons become triangle fans (the reference drops them,
+                                  core/ObjLoader.cpp:151-154) and negative indices count from the end */
 typedef struct rt_mesh rt_mesh;
 int rt_mesh_load_obj(const char *path, unsigned loader, rt_mesh **out);
 /* Wraps caller arrays (copied).  normals/materials may be NULL with a zero count. */

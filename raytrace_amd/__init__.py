@@ -24,7 +24,7 @@ MODELS_DIR = os.path.join(REPO_ROOT, "assets", "models")
 
 RAY_FLOATS = 16          # one 64-byte RayIntersection record = 16 x 4 bytes
 MISS_ID = 0xFFFFFFFF
-LOADER = {"reference": 0, "tolerant": 1}
+LOADER = {"reference": 0, "tolerant": 1, "extended": 2}
 BVH_MODE = {"reference": 0, "fixed": 1, "sah": 2}
 
 

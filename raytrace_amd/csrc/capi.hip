@@ -312,7 +312,7 @@ int rt_device_count(void)
 int rt_mesh_load_obj(const char *path, unsigned loader, rt_mesh **out)
 {
   if (!path || !out) return Fail(RT_ERR_INVALID, "null argument");
-  if (loader > RT_LOADER_TOLERANT) return Fail(RT_ERR_INVALID, "unknown loader mode");
+  if (loader > RT_LOADER_EXTENDED) return Fail(RT_ERR_INVALID, "unknown loader mode");
   rt_mesh *m = new (std::nothrow) rt_mesh;
   if (!m) return Fail(RT_ERR_NOMEM, "out of memory");
   try {

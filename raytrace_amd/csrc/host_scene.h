@@ -32,6 +32,7 @@ struct MtlLib {
 enum LoaderMode : unsigned {
   kLoaderReference = 0,  // one token per delimiter: repeated spaces yield empty tokens (core/ObjLoader.cpp:12-34)
   kLoaderTolerant = 1,   // empty tokens from repeated / trailing spaces are dropped; all else identical
+  kLoaderExtended = 2,   // tolerant + quads / n-gons fanned into triangles + negative (relative) indices
 };
 
 struct Mesh {

@@ -162,25 +162,35 @@ void LoadObj(std::istream &file, Mesh &mesh, std::string const &folder, LoaderMo
       rd.Tokens();
       if (rd.tok.size() < 4) {
         mesh.log.push_back("incomplete face record, ignoring");
-      } else if (rd.tok.size() > 4) {
+      } else if (rd.tok.size() > 4 && mode != kLoaderExtended) {
         mesh.log.push_back("Quads and ngons not supported, ignoring.");
       } else {
-        Corner c0(rd.tok[1]), c1(rd.tok[2]), c2(rd.tok[3]);
-        if (!c0.HasVertex() || !c1.HasVertex() || !c2.HasVertex()) {
-          mesh.log.push_back("face record missing vertex index, skipping");
-          continue;
+        // One triangle in the reference and tolerant modes; a fan (c0, c_i, c_i+1) over quads and n-gons in the
+        // extended mode, which also resolves the negative, count-relative indices OBJ allows.
+        auto index = [&](std::string const &field, size_t count) -> unsigned {
+          const long v = std::atol(field.c_str());
+          if (mode == kLoaderExtended && v < 0) return static_cast<unsigned>(static_cast<long>(count) + v);
+          return static_cast<unsigned>(v) - 1;
+        };
+        Corner c0(rd.tok[1]);
+        for (size_t k = 2; k + 1 < rd.tok.size(); ++k) {
+          Corner c1(rd.tok[k]), c2(rd.tok[k + 1]);
+          if (!c0.HasVertex() || !c1.HasVertex() || !c2.HasVertex()) {
+            mesh.log.push_back("face record missing vertex index, skipping");
+            break;
+          }
+          rt_face face{};
+          face.s[0] = index(c0.f[0], vertices.size());
+          face.s[1] = index(c1.f[0], vertices.size());
+          face.s[2] = index(c2.f[0], vertices.size());
+          face.s[3] = static_cast<unsigned>(curr_mat_index);
+          if (c0.HasNormal() && c1.HasNormal() && c2.HasNormal()) {
+            face.s[4] = index(c0.f[2], normals.size());
+            face.s[5] = index(c1.f[2], normals.size());
+            face.s[6] = index(c2.f[2], normals.size());
+          }
+          faces.push_back(face);
         }
-        rt_face face{};
-        face.s[0] = static_cast<unsigned>(std::atoi(c0.f[0].c_str())) - 1;
-        face.s[1] = static_cast<unsigned>(std::atoi(c1.f[0].c_str())) - 1;
-        face.s[2] = static_cast<unsigned>(std::atoi(c2.f[0].c_str())) - 1;
-        face.s[3] = static_cast<unsigned>(curr_mat_index);
-        if (c0.HasNormal() && c1.HasNormal() && c2.HasNormal()) {
-          face.s[4] = static_cast<unsigned>(std::atol(c0.f[2].c_str())) - 1;
-          face.s[5] = static_cast<unsigned>(std::atol(c1.f[2].c_str())) - 1;
-          face.s[6] = static_cast<unsigned>(std::atol(c2.f[2].c_str())) - 1;
-        }
-        faces.push_back(face);
       }
     } else if (ty == "mtllib") {
       rd.Tokens();

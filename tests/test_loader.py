@@ -81,3 +81,31 @@ def test_cube_mirror_materials(rt):
     assert len(m.materials) == 6 and len(m.normals) == 12
     assert m.faces[0].tolist() == [1, 2, 0, 4, 0, 0, 0, 0]
     assert m.material_index("Mirror") == 2 and m.materials[2, 9] == 1.0 and m.materials[1, 9] == 0.0
+
+
+def test_extended_loader_fans_polygons_and_resolves_relative_indices(rt, tmp_path):
+    """The reference drops every face with more than three corners (core/ObjLoader.cpp:151-154); the extended mode
+    turns them into triangle fans and accepts OBJ's negative indices.  Triangles-only files load identically."""
+    text = ("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 1.5 0\nvn 0 0 1\n"
+            "f 1 2 3 4\n"            # quad -> (1,2,3) (1,3,4)
+            "f 1//1 2//1 3//1 4//1 5//1\n"   # pentagon -> three triangles, normals kept
+            "f -5 -4 -3\n"           # relative: vertices 1 2 3
+            "f 1 2 3\n")
+    p = _write(tmp_path, "poly.obj", text)
+    ext = rt.Mesh.load_obj(p, "extended")
+    assert len(ext.faces) == 2 + 3 + 1 + 1
+    assert ext.faces[:2, :3].tolist() == [[0, 1, 2], [0, 2, 3]]
+    assert ext.faces[2:5, :3].tolist() == [[0, 1, 2], [0, 2, 3], [0, 3, 4]] and np.all(ext.faces[2:5, 4:7] == 0)
+    assert ext.faces[5, :3].tolist() == [0, 1, 2] and ext.faces[6, :3].tolist() == [0, 1, 2]
+    tol = rt.Mesh.load_obj(p, "tolerant")
+    assert len(tol.faces) == 2 and "Quads and ngons not supported, ignoring." in tol.log   # polygons dropped, as the reference does
+    for model in ("teapot.obj", "cube_mirror_test.obj", "bunny.obj"):
+        a = rt.Mesh.load_obj(os.path.join(MODELS, model), "tolerant")
+        b = rt.Mesh.load_obj(os.path.join(MODELS, model), "extended")
+        assert np.array_equal(a.faces, b.faces) and np.array_equal(a.verts, b.verts)
+    wheel_t = rt.Mesh.load_obj(os.path.join(MODELS, "wheel.obj"), "tolerant")
+    wheel_e = rt.Mesh.load_obj(os.path.join(MODELS, "wheel.obj"), "extended")
+    assert len(wheel_e.faces) >= len(wheel_t.faces)
+    bvh = rt.BVH(wheel_e, "sah")
+    sc = rt.Scene(wheel_e, bvh, device=-1)     # the fanned mesh flattens
+    sc.close()
