@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--raygen", default="table", choices=["table", "device"],
                     help="table: rays are a RayIntersection array resident in HBM (the reference's interface); device: "
                          "the same primary rays are generated inside the kernel (rt_trace_primary), no ray array is read")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 flow on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--frames", type=int, default=4,
                     help="image workloads: distinct camera positions (ray tables, all resident in HBM) the steps cycle "
                          "through, so that no step repeats the previous step's rays")
@@ -111,12 +114,18 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if a.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    red_dev = "cuda" if a.backend == "nccl" else "cpu"   # where the two scalar reductions below live
 
     model, W, H = WORKLOADS[a.workload]
     mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "reference" if a.workload == "mirror5" else "tolerant")
@@ -238,10 +247,10 @@ def main():
     dev_ms = ev0.elapsed_time(ev1) / max(1, a.steps)  # mean launch duration on the launch stream
     dev_ms /= passes
     if dist:
-        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([wall], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
-        nn = torch.tensor([n_local], dtype=torch.float64, device="cuda")
+        nn = torch.tensor([n_local], dtype=torch.float64, device=red_dev)
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)
         n_total = int(nn.item())
     else:
