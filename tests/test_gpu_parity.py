@@ -17,6 +17,7 @@ from test_oracle import random_pairs
 
 pytestmark = pytest.mark.gpu
 
+f32 = np.float32
 REL = 1e-5  # tolerance for the floating-point outputs that are not bit-pinned (hit point, normal)
 
 
@@ -350,3 +351,61 @@ def test_rays_generated_in_the_kernel_equal_the_table(rt, gpu, W, H):
     with pytest.raises(rt.RtError):
         scene.trace_primary(0, 4, origin, 1, None)
     scene.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_triangle_soups_at_many_scales(rt, oracle, gpu, seed):
+    """Seeded triangle soups (slivers, axis-aligned flats, duplicates, far-off and tiny clusters) at scene scales
+    from 1e-3 to 1e5 and ray families that stress the conservative box test -- grazing, axis-parallel, origins
+    inside the scene, origins far away: every builder, width and box encoding must return the oracle's bits."""
+    rng = np.random.default_rng(1000 + seed)
+    scale = f32(10.0 ** rng.uniform(-3, 5))
+    offset = (rng.uniform(-1, 1, 3) * scale * f32(10.0 ** rng.uniform(-1, 2))).astype(f32)
+    nt = int(rng.integers(40, 400))
+    c = rng.uniform(-1, 1, (nt, 1, 3))
+    tri = c + rng.normal(0, 1, (nt, 3, 3)) * 10.0 ** rng.uniform(-3, -0.5, (nt, 1, 1))
+    tri[::7, :, int(rng.integers(3))] = tri[::7, :1, int(rng.integers(3))]        # axis-aligned flat triangles
+    tri[5::11, 2] = tri[5::11, 0] + (tri[5::11, 1] - tri[5::11, 0]) * 0.5 + 1e-7  # slivers
+    tri[3::13] = tri[2::13][: len(tri[3::13])]                                    # exact duplicates
+    verts = np.ones((nt * 3, 4), f32)
+    verts[:, :3] = (tri.reshape(-1, 3) * scale).astype(f32) + offset
+    faces = np.zeros((nt, 8), np.uint32)
+    faces[:, :3] = np.arange(nt * 3).reshape(nt, 3)
+    mesh = rt.Mesh.from_arrays(verts, faces)
+    lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
+    n = 6000
+    o = np.empty((n, 3), f32); d = np.empty((n, 3), f32)
+    k = n // 4
+    pick = rng.integers(0, nt, n)
+    bary = rng.dirichlet((1, 1, 1), n).astype(f32)
+    corners = verts[:, :3].reshape(nt, 3, 3)[pick]
+    target = (corners * bary[:, :, None]).sum(1).astype(f32)                                 # a point on a triangle
+    target[::5] += (rng.normal(0, 1, (len(target[::5]), 3)) * scale * 0.01).astype(f32)      # ... or just beside one
+    o[:k] = (lo + (hi - lo) * rng.uniform(0, 1, (k, 3))).astype(f32)                       # inside the scene
+    o[k:2 * k] = (lo - (hi - lo) * rng.uniform(1, 50, (k, 3))).astype(f32)                  # far away
+    o[2 * k:3 * k] = target[2 * k:3 * k] + (rng.normal(0, 1, (k, 3)) * scale * 3).astype(f32)
+    o[3 * k:] = target[3 * k:].copy()
+    d[:] = target - o
+    axis = rng.integers(0, 3, n - 3 * k)
+    o[3 * k:, :] -= 0                                                                       # axis-parallel family:
+    d[3 * k:] = 0
+    d[np.arange(3 * k, n), axis] = rng.choice([-1, 1], n - 3 * k) * scale
+    o[3 * k:] = target[3 * k:] - d[3 * k:] * f32(2.5)
+    d[::17] *= f32(1e-6); d[1::17] *= f32(1e6)                                              # unnormalised directions
+    rays = np.zeros((n, 16), f32)
+    rays[:, 0:3] = o; rays[:, 3] = 1; rays[:, 4:7] = d
+    oid, ot, ou, ov = oracle.closest_hit(mesh.verts, mesh.faces, rays)
+    assert (oid != rt.MISS_ID).sum() > 50      # tiny scales lose most hits to the reference's |det| <= 1e-6 rejection
+    for mode in ("fixed", "sah"):
+        bvh = rt.BVH(mesh, mode)
+        for width in (2, 4):
+            scene = rt.Scene(mesh, bvh, device=gpu, width=width)
+            for quant in (1, 0):
+                scene.set_param("quantized", quant)
+                ids, t, u, v = rt.hit_fields(scene.intersect(rays))
+                bad = np.flatnonzero(ids != oid)
+                assert len(bad) == 0, (mode, width, quant, float(scale), bad[:5], ids[bad[:5]], oid[bad[:5]])
+                h = oid != rt.MISS_ID
+                for a, b in ((t, ot), (u, ou), (v, ov)):
+                    assert np.array_equal(bits(a[h]), bits(b[h])), (mode, width, quant)
+            scene.close()
