@@ -129,7 +129,7 @@ void FillArgs(const rt_scene *s, rt::KernelArgs &a)
   a.nnormals = static_cast<uint32_t>(s->nnormals);
   a.nmats = static_cast<uint32_t>(s->nmats);
   // at least 16 entries per lane: the output stage exchanges the wave's 64 x 64-byte records through the stack
-  a.stack_entries = static_cast<uint32_t>(std::max(16, (s->width == 4 ? s->flat.stack4 : s->flat.stack2) + 1 + s->extra_stack));
+  a.stack_entries = static_cast<uint32_t>(std::max(16, (s->width == 4 ? s->flat.stack4 : s->flat.stack2) + s->extra_stack));
   a.scale = s->flat.scale;
   a.leaf_pct = static_cast<uint32_t>(s->leaf_pct);
   a.stats = s->d_stats;

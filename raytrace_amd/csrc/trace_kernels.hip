@@ -116,11 +116,8 @@ __device__ __forceinline__ uint32_t Step4(const KernelArgs &p, const RayCtx &r, 
 }
 
 // Quantized records: WIDTH children of 16 bytes each {x, y, z axis words, reference}.
-// Two-wide quantized step.  The top of the traversal stack lives in the register `tos`; LDS row r holds the entry
-// below r entries of the logical stack, so a pop hands out the register at once and its refill from LDS is not
-// waited for before the next pop or push.
 __device__ __forceinline__ uint32_t Step2Q(const KernelArgs &p, const RayCtxQ &q, uint32_t cur, float tbest,
-                                           uint32_t *stk, uint32_t &sp, uint32_t &tos)
+                                           uint32_t *stk, uint32_t &sp)
 {
   const uint4 *np = reinterpret_cast<const uint4 *>(p.nodes) + static_cast<size_t>(cur) * 2u;
   const uint4 c0 = np[0], c1 = np[1];
@@ -129,17 +126,14 @@ __device__ __forceinline__ uint32_t Step2Q(const KernelArgs &p, const RayCtxQ &q
   const bool h1 = SlabTestQ(q, c1.x, c1.y, c1.z, tbest, t1);
   if (h0 && h1) {
     const bool swap = t1 < t0;
-    stk[sp * 64u] = tos;
-    tos = swap ? c0.w : c1.w;
+    stk[sp * 64u] = swap ? c0.w : c1.w;
     sp++;
     return swap ? c1.w : c0.w;
   }
   if (h0) return c0.w;
   if (h1) return c1.w;
   if (sp == 0) return kDone;
-  const uint32_t next = tos;
-  tos = stk[--sp * 64u];
-  return next;
+  return stk[--sp * 64u];
 }
 
 __device__ __forceinline__ uint32_t Step4Q(const KernelArgs &p, const RayCtxQ &q, uint32_t cur, float tbest,
@@ -269,7 +263,7 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
       RayCtxQ rq;
       if (QUANT) SetupRayQ(rq, r, p.grid, p.scale);
       Best best{kFltMax, 0.f, 0.f, RT_MISS_ID};
-      uint32_t sp = 0, cur = live ? 0u : kDone, tos = kDone;
+      uint32_t sp = 0, cur = live ? 0u : kDone;
       uint32_t nnode = 0, ntri = 0, nleaf = 0;
 
       // One wave-uniform decision per iteration: take a node step (lanes holding an inner reference) or a
@@ -289,18 +283,14 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
           if (inner) {
             if (COUNT) nnode++;
             if (QUANT)
-              cur = (WIDTH == 4) ? Step4Q(p, rq, cur, best.t, stk, sp) : Step2Q(p, rq, cur, best.t, stk, sp, tos);
+              cur = (WIDTH == 4) ? Step4Q(p, rq, cur, best.t, stk, sp) : Step2Q(p, rq, cur, best.t, stk, sp);
             else
               cur = (WIDTH == 4) ? Step4(p, r, cur, best.t, stk, sp) : Step2(p, r, cur, best.t, stk, sp);
           }
         } else if (parked) {
           if (COUNT) nleaf += (cur & 7u) ? 1u : 0u;
           LeafTest<COUNT>(p, r, cur, best, ntri);
-          if (QUANT && WIDTH == 2) {
-            if (sp) { cur = tos; tos = stk[--sp * 64u]; } else cur = kDone;
-          } else {
-            cur = sp ? stk[--sp * 64u] : kDone;
-          }
+          cur = sp ? stk[--sp * 64u] : kDone;
         }
       }
 
