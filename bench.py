@@ -294,6 +294,15 @@ def main():
             "stream_GBs": round((in_b + out_b) * n_local / (dev_ms * 1e-3) / 1e9, 1),
             "traversal_GBs": round((bytes_per_ray - in_b - out_b) * n_local / (dev_ms * 1e-3) / 1e9, 1),
         }
+        # The resource this kernel actually saturates is FP32 vector issue, not memory: algorithmic lane operations
+        # (24 per box test, two boxes per node record; 52 per triangle test incl. the divide) against the rate at
+        # which 256 CUs x 64 lanes retire one non-fused operation per clock at 2.4 GHz.  The issue and lane
+        # utilisation measured by PMC counters are in the committed profile summary.
+        ops_per_ray = n_node * (4 if width == 4 else 2) * 24 + n_tri * 52
+        roofline["valu"] = {"algorithmic_ops_per_ray": round(ops_per_ray, 1),
+                            "achieved_Tops": round(ops_per_ray * n_local / (dev_ms * 1e-3) / 1e12, 2),
+                            "peak_Tops": round(256 * 64 * 2.4e9 / 1e12, 1),
+                            "frac": round(ops_per_ray * n_local / (dev_ms * 1e-3) / (256 * 64 * 2.4e9), 4)}
         # HBM-side bytes per launch from PMC counters: measured in separate rocprofv3 passes (tools/profile_gpu.sh),
         # committed next to the kernel-trace summary, looked up here by workload and output record
         roofline["traffic"], roofline["traffic_source"] = measured_traffic(a.workload, out_b, world)
