@@ -141,6 +141,10 @@ def main():
         scene.set_param("block_threads", a.block)
     if W and a.workload != "tiles4k" and a.image_hint:
         scene.set_param("image_width", W)
+    elif a.workload == "tiles4k" and a.image_hint and W % a.tile == 0:
+        # a rank's rays are its tiles one after another, each row-major and a.tile pixels wide: to the library that
+        # is an image a.tile wide and (tiles x rows) tall, so waves still take 8x8 pixel blocks
+        scene.set_param("image_width", a.tile)
     scene.set_param("feedback", a.feedback)
     if a.feedback_radius >= 0:
         scene.set_param("feedback_radius", a.feedback_radius)
