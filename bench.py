@@ -84,8 +84,6 @@ def parse():
                          "through, so that no step repeats the previous step's rays")
     ap.add_argument("--feedback-radius", type=int, default=-1, help="-1 = library default")
     ap.add_argument("--feedback-share", type=int, default=-1, help="-1 = library default")
-    ap.add_argument("--refill", type=int, default=-1,
-                    help="unstructured launches: refill finished lanes once this many are idle (-1: 32 for the ao workload, else off)")
     ap.add_argument("--feedback", type=int, default=1,
                     help="1: each launch starts its work units costliest-first, by the costs measured two launches earlier")
     return ap.parse_args()
@@ -148,8 +146,6 @@ def main():
         # is an image a.tile wide and (tiles x rows) tall, so waves still take 8x8 pixel blocks
         scene.set_param("image_width", a.tile)
     scene.set_param("feedback", a.feedback)
-    refill = a.refill if a.refill >= 0 else (32 if a.workload == "ao" else 0)
-    scene.set_param("refill", refill)
     if a.feedback_radius >= 0:
         scene.set_param("feedback_radius", a.feedback_radius)
     if a.feedback_share >= 0:

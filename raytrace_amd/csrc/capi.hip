@@ -97,8 +97,6 @@ struct rt_scene {
   int waves_per_cu = 0;          // optional resident-wave cap per CU, held through the LDS stack size (0 = none)
   int feedback_share = 96;       // ... scaled by this many 128ths
   int feedback_radius = 1;       // a unit's measured cost also counts for its neighbours this many units away
-  int refill = 0;                // unstructured launches: hand finished lanes new rays once this many idle (0 = never)
-  int refill_span = 8;           // ... from a run of this many x 64 consecutive records per wave
   int leaf_pct = 50;             // node/leaf step scheduling threshold (percent of busy lanes parked at a leaf)
   int extra_stack = 0;           // diagnostic: extra LDS stack entries per lane (lowers occupancy)
   int image_width = 0;           // hint: ray arrays are row-major images of this width (0 = unstructured)
@@ -203,12 +201,6 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
       a.order = s->d_order;
     }
   }
-  const bool refill = s->refill > 0 && mode == rt::kModeIntersect && a.img_w == 0 && !count;
-  if (refill) {
-    a.span = 64u * static_cast<uint32_t>(s->refill_span);
-    a.refill = static_cast<uint32_t>(s->refill);
-    a.ntasks = (a.n + a.span - 1u) / a.span;
-  }
   const uint32_t block = static_cast<uint32_t>(s->block_threads), wpb = block / 64u;
   if (s->waves_per_cu > 0) {
     // Sizing the LDS stack so that exactly this many waves' workgroups fit holds the cap whatever the register
@@ -259,8 +251,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
   if (static_cast<size_t>(a.stack_entries) * 1024u > 160u * 1024u)
     return Fail(RT_ERR_INVALID, "bvh too deep for the LDS traversal stack");
   {
-    hipError_t e_ = refill ? rt::LaunchClosestHitRefill(a, s->width, s->quant != 0, grid, block, stream)
-                           : rt::LaunchClosestHit(a, s->width, s->quant != 0, mode, count, grid, block, stream);
+    hipError_t e_ = rt::LaunchClosestHit(a, s->width, s->quant != 0, mode, count, grid, block, stream);
     if (e_ != hipSuccess)
       return Fail(RT_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(e_) + " (grid " + std::to_string(grid) +
                                      ", block " + std::to_string(block) + ", stack entries " + std::to_string(a.stack_entries) + ")");
@@ -550,12 +541,6 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "feedback_radius") {
     if (value < 0 || value > 3) return Fail(RT_ERR_INVALID, "feedback_radius must be in 0..3");
     s->feedback_radius = value;
-  } else if (k == "refill") {
-    if (value < 0 || value > 64) return Fail(RT_ERR_INVALID, "refill must be in 0..64");
-    s->refill = value;
-  } else if (k == "refill_span") {
-    if (value < 1 || value > 1024) return Fail(RT_ERR_INVALID, "refill_span must be in 1..1024");
-    s->refill_span = value;
   } else if (k == "centre_first") {
     s->centre_first = value != 0;
   } else if (k == "leaf_pct") {

@@ -39,8 +39,6 @@ struct KernelArgs {
   uint32_t ntasks;            // wave-sized work items: ceil(n/64), or the number of 8x8 tiles
   uint32_t cost_radius;       // a unit's cost is also recorded for its neighbours within this many units (<= 3)
   uint32_t cost_share;        // ... scaled by this many 128ths
-  uint32_t span;              // refill launches: consecutive records per wave
-  uint32_t refill;            // refill launches: idle lanes that trigger a refill
   uint32_t nnormals;
   uint32_t nmats;
   uint32_t stack_entries;     // LDS stack entries per lane
@@ -55,9 +53,6 @@ struct KernelArgs {
 
 hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool count, uint32_t grid,
                             uint32_t block, hipStream_t stream);
-// Launch for unstructured, incoherent ray arrays: waves own runs of a.span records and refill idle lanes.
-hipError_t LaunchClosestHitRefill(const KernelArgs &a, int width, bool quant, uint32_t grid, uint32_t block,
-                                  hipStream_t stream);
 // order[k] = k-th unit to start, costliest bin first, index order within a bin (one 512-thread workgroup).
 // unit_cost must hold 512 * BuildOrderKeysPerThread(nunits) entries; it is zeroed after being read.
 uint32_t BuildOrderKeysPerThread(uint32_t nunits);

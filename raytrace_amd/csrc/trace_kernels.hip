@@ -170,38 +170,6 @@ __device__ __forceinline__ uint32_t Step4Q(const KernelArgs &p, const RayCtxQ &q
 
 __device__ __forceinline__ float Dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-// Hit point and normal of the closest hit (render_client/tracekernel.ck:373-399): the point is the barycentric
-// combination of the original vertices, the normal the reference's u*N[n0] + v*N[n1] + (1-u-v)*N[n2]
-// (its pairing, tracekernel.ck:376) or, in scenes without vertex normals, the unit geometric normal.
-__device__ __forceinline__ void HitGeometry(const KernelArgs &p, const Best &best, rt_face &f, float &px, float &py, float &pz,
-                                            float &nx, float &ny, float &nz)
-{
-  f = p.faces[best.id];
-  const float u = best.u, v = best.v, w = 1.f - u - v;
-  const float4 v0 = *reinterpret_cast<const float4 *>(p.verts + f.s[0]);
-  const float4 v1 = *reinterpret_cast<const float4 *>(p.verts + f.s[1]);
-  const float4 v2 = *reinterpret_cast<const float4 *>(p.verts + f.s[2]);
-  px = w * v0.x + u * v1.x + v * v2.x;
-  py = w * v0.y + u * v1.y + v * v2.y;
-  pz = w * v0.z + u * v1.z + v * v2.z;
-  if (f.s[4] < p.nnormals && f.s[5] < p.nnormals && f.s[6] < p.nnormals) {
-    const float4 *np4 = reinterpret_cast<const float4 *>(p.normals);
-    const float4 n0 = np4[f.s[4]], n1 = np4[f.s[5]], n2 = np4[f.s[6]];
-    nx = u * n0.x + v * n1.x + w * n2.x;
-    ny = u * n0.y + v * n1.y + w * n2.y;
-    nz = u * n0.z + v * n1.z + w * n2.z;
-  } else {
-    const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
-    const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
-    nx = e1y * e2z - e1z * e2y; ny = e1z * e2x - e1x * e2z; nz = e1x * e2y - e1y * e2x;
-    const float len2 = nx * nx + ny * ny + nz * nz;
-    if (len2 > 0.f) {   // one hardware reciprocal square root (1 ulp) instead of a square root and three divides
-      const float inv_len = __builtin_amdgcn_rsqf(len2);
-      nx *= inv_len; ny *= inv_len; nz *= inv_len;
-    }
-  }
-}
-
 // Where a wave's work unit sits: the first record of a linear run, or the pixel origin of an 8x8 tile.
 struct UnitPos {
   uint32_t first;    // linear: index of lane 0's record
@@ -345,11 +313,32 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
           out_n = LoadF4(rp + 2);  // terminated record passes through unchanged
         }
         if (hit) {
-          rt_face f;
-          float px, py, pz, nx, ny, nz;
-          HitGeometry(p, best, f, px, py, pz, nx, ny, nz);
-          const float u = best.u, v = best.v;
-          out_o = make_float4(px, py, pz, 1.f);
+          const rt_face f = p.faces[best.id];
+          const float u = best.u, v = best.v, w = 1.f - u - v;
+          const float4 v0 = *reinterpret_cast<const float4 *>(p.verts + f.s[0]);
+          const float4 v1 = *reinterpret_cast<const float4 *>(p.verts + f.s[1]);
+          const float4 v2 = *reinterpret_cast<const float4 *>(p.verts + f.s[2]);
+          out_o = make_float4(w * v0.x + u * v1.x + v * v2.x, w * v0.y + u * v1.y + v * v2.y,
+                              w * v0.z + u * v1.z + v * v2.z, 1.f);
+          float nx, ny, nz;
+          if (f.s[4] < p.nnormals && f.s[5] < p.nnormals && f.s[6] < p.nnormals) {
+            // u*N[n0] + v*N[n1] + (1-u-v)*N[n2]: the reference's pairing (tracekernel.ck:376)
+            const float4 *np4 = reinterpret_cast<const float4 *>(p.normals);
+            const float4 n0 = np4[f.s[4]], n1 = np4[f.s[5]], n2 = np4[f.s[6]];
+            nx = u * n0.x + v * n1.x + w * n2.x;
+            ny = u * n0.y + v * n1.y + w * n2.y;
+            nz = u * n0.z + v * n1.z + w * n2.z;
+          } else {
+            // no vertex normals in the scene: unit geometric normal
+            const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
+            const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
+            nx = e1y * e2z - e1z * e2y; ny = e1z * e2x - e1x * e2z; nz = e1x * e2y - e1y * e2x;
+            const float len2 = nx * nx + ny * ny + nz * nz;
+            if (len2 > 0.f) {   // one hardware reciprocal square root (1 ulp) instead of a square root and three divides
+              const float inv_len = __builtin_amdgcn_rsqf(len2);
+              nx *= inv_len; ny *= inv_len; nz *= inv_len;
+            }
+          }
           out_n = make_float4(nx, ny, nz, 0.f);
           out_d = make_float4(dx, dy, dz, 0.f);
           out_u = u; out_v = v;
@@ -435,103 +424,6 @@ __global__ void __launch_bounds__(256) ClosestHitKernel(KernelArgs p)
       }
     }
   }
-}
-
-// Closest hit for UNSTRUCTURED ray arrays whose rays differ wildly in length (secondary rays): a wave owns a run
-// of `p.span` consecutive records and, whenever `p.refill` or more of its lanes have finished their ray, hands
-// those lanes the next records of the run.  With one ray per lane for the whole life of the wave, lanes whose
-// ray left the scene after three steps idle until the longest ray of the 64 is done -- 31 % lane utilisation
-// on ambient-occlusion style rays; refilling brings the lockstep model to 57 %.  Coherent rays lose their
-// coherence this way, so image-shaped launches never take this kernel.  Per ray the traversal is the same
-// code in the same order as ClosestHitKernel, so every record is bit-identical.
-template <int WIDTH, bool QUANT>
-__global__ void __launch_bounds__(256) ClosestHitRefillKernel(KernelArgs p)
-{
-  extern __shared__ uint32_t lds_stack[];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t *stk = lds_stack + wave * p.stack_entries * 64u + lane;
-  const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (slot >= p.ntasks) return;
-  uint32_t unit = slot;
-  if (p.order) unit = p.order[unit];
-  unit = __builtin_amdgcn_readfirstlane(unit);
-  uint32_t next = unit * p.span;                                   // wave-uniform cursor into the run
-  const uint32_t end = min(p.n, next + p.span);
-
-  RayCtx r;
-  RayCtxQ rq;
-  Best best{kFltMax, 0.f, 0.f, RT_MISS_ID};
-  uint32_t idx = 0, sp = 0, cur = kDone, iters = 0, unused = 0;
-  bool have = false;                                               // this lane holds a ray whose record is not written yet
-
-  auto emit = [&]() {
-    const bool hit = best.id != RT_MISS_ID;
-    if (p.hits16)
-      *reinterpret_cast<float4 *>(p.hits16 + idx) =
-          make_float4(__uint_as_float(best.id), best.t, hit ? best.u : 0.f, hit ? best.v : 0.f);
-    if (p.hits) {
-      const float4 *rp = reinterpret_cast<const float4 *>(p.rays + idx);
-      const float4 in_o = LoadF4(rp), in_d = LoadF4(rp + 1);
-      float4 out_o = in_o, out_n = in_d;
-      float out_u = 0.f, out_v = 0.f;
-      if (hit) {
-        rt_face f;
-        float px, py, pz, nx, ny, nz;
-        HitGeometry(p, best, f, px, py, pz, nx, ny, nz);
-        out_o = make_float4(px, py, pz, 1.f);
-        out_n = make_float4(nx, ny, nz, 0.f);
-        out_u = best.u; out_v = best.v;
-      }
-      float4 *op = reinterpret_cast<float4 *>(p.hits + idx);
-      op[0] = out_o;
-      op[1] = make_float4(in_d.x, in_d.y, in_d.z, hit ? 0.f : in_d.w);
-      op[2] = out_n;
-      op[3] = make_float4(out_u, out_v, __uint_as_float(best.id), best.t);
-    }
-  };
-
-  for (;;) {
-    const unsigned long long idle = __ballot(cur == kDone);
-    const uint32_t nidle = __popcll(idle);
-    if (next >= end && nidle == 64u) break;
-    if (next < end && (nidle >= p.refill || nidle == 64u)) {
-      if (cur == kDone) {
-        if (have) emit();
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32),
-                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
-        idx = next + rank;
-        have = idx < end;
-        if (have) {
-          const float4 *rp = reinterpret_cast<const float4 *>(p.rays + idx);
-          const float4 in_o = LoadF4(rp), in_d = LoadF4(rp + 1);
-          SetupRay(r, in_o.x, in_o.y, in_o.z, in_d.x, in_d.y, in_d.z, p.scale);
-          if (QUANT) SetupRayQ(rq, r, p.grid, p.scale);
-          best = Best{kFltMax, 0.f, 0.f, RT_MISS_ID};
-          sp = 0;
-          cur = 0u;
-        }
-      }
-      next = min(end, next + nidle);
-    }
-    iters++;
-    const bool inner = !(cur & kLeafBitDev);
-    const bool parked = !inner && cur != kDone;
-    const unsigned long long mi = __ballot(inner), ml = __ballot(parked);
-    const uint32_t ni = __popcll(mi), nl = __popcll(ml);
-    if (ni != 0u && nl * 100u < p.leaf_pct * (ni + nl)) {
-      if (inner) {
-        if (QUANT)
-          cur = (WIDTH == 4) ? Step4Q(p, rq, cur, best.t, stk, sp) : Step2Q(p, rq, cur, best.t, stk, sp);
-        else
-          cur = (WIDTH == 4) ? Step4(p, r, cur, best.t, stk, sp) : Step2(p, r, cur, best.t, stk, sp);
-      }
-    } else if (parked) {
-      LeafTest<false>(p, r, cur, best, unused);
-      cur = sp ? stk[--sp * 64u] : kDone;
-    }
-  }
-  if (have) emit();
-  if (p.unit_cost && lane == 0) atomicMax(p.unit_cost + unit, iters);
 }
 
 // Counting sort of work units by cost bin (cost / 16, capped), costliest bin first, ascending unit index inside
@@ -658,20 +550,6 @@ hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode
                  : LaunchLayout<4, false>(a, mode, count, grid, block, lds, stream);
   return quant ? LaunchLayout<2, true>(a, mode, count, grid, block, lds, stream)
                : LaunchLayout<2, false>(a, mode, count, grid, block, lds, stream);
-}
-
-hipError_t LaunchClosestHitRefill(const KernelArgs &a, int width, bool quant, uint32_t grid, uint32_t block, hipStream_t stream)
-{
-  const size_t lds = static_cast<size_t>(a.stack_entries) * 4u * block;
-  (void)hipGetLastError();
-  if (width == 4) {
-    if (quant) hipLaunchKernelGGL((ClosestHitRefillKernel<4, true>), dim3(grid), dim3(block), lds, stream, a);
-    else hipLaunchKernelGGL((ClosestHitRefillKernel<4, false>), dim3(grid), dim3(block), lds, stream, a);
-  } else {
-    if (quant) hipLaunchKernelGGL((ClosestHitRefillKernel<2, true>), dim3(grid), dim3(block), lds, stream, a);
-    else hipLaunchKernelGGL((ClosestHitRefillKernel<2, false>), dim3(grid), dim3(block), lds, stream, a);
-  }
-  return hipGetLastError();
 }
 
 uint32_t BuildOrderKeysPerThread(uint32_t nunits) { return ((nunits + 511u) / 512u + 31u) / 32u * 32u; }

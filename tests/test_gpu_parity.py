@@ -409,39 +409,3 @@ def test_random_triangle_soups_at_many_scales(rt, oracle, gpu, seed):
                 for a, b in ((t, ot), (u, ou), (v, ov)):
                     assert np.array_equal(bits(a[h]), bits(b[h])), (mode, width, quant)
             scene.close()
-
-
-def test_lane_refill_returns_the_same_records(rt, oracle, gpu):
-    """The refilling launch for unstructured ray arrays changes which lane traces which ray and when, nothing else:
-    records must equal the plain launch's bit for bit, for every threshold, run length, ragged size and layout."""
-    import torch
-    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny_big.obj"), "tolerant")
-    bvh = rt.BVH(mesh, "sah")
-    rays = rt.ao_rays(mesh, bvh.root_box, 99, 0, 200_000)
-    scene = rt.Scene(mesh, bvh, device=gpu)
-    base = scene.intersect(rays)
-    compare(rt, oracle, mesh, rays, base, np.arange(0, len(rays), 211))
-    for width, quant in ((2, 1), (4, 1), (2, 0)):
-        scene.set_param("width", width)
-        scene.set_param("quantized", quant)
-        for refill, span, fb in ((32, 8, 0), (1, 8, 0), (64, 2, 0), (16, 1, 1), (32, 64, 1)):
-            scene.set_param("refill", refill)
-            scene.set_param("refill_span", span)
-            scene.set_param("feedback", fb)
-            for n in (len(rays), 64 * span * 3 + 5, 63, 1):
-                for rep in range(3 if fb else 1):
-                    out = scene.intersect(rays[:n])
-                    assert np.array_equal(bits(out), bits(base[:n])), (width, quant, refill, span, fb, n, rep)
-    # compact records too
-    scene.set_param("width", 2); scene.set_param("quantized", 1); scene.set_param("refill", 32); scene.set_param("feedback", 0)
-    d = torch.from_numpy(rays).cuda()
-    c = torch.zeros((len(rays), 4), dtype=torch.float32, device="cuda")
-    scene.intersect_async(d.data_ptr(), len(rays), None, c.data_ptr())
-    torch.cuda.synchronize()
-    ids, t, u, v = rt.hit_fields(base)
-    got = c.cpu().numpy()
-    assert np.array_equal(got[:, 0].view(np.uint32), ids) and np.array_equal(bits(got[:, 1]), bits(t))
-    # image-shaped launches ignore the knob
-    scene.set_param("image_width", 500)
-    assert np.array_equal(bits(scene.intersect(rays)), bits(base))
-    scene.close()
