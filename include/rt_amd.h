@@ -122,7 +122,7 @@ int rt_scene_info(const rt_scene *s, uint64_t info[8]);
  *                    launches.  Defaults 1 and 96; 0 and anything = exact per-unit costs, best for repeated rays.
  *   "leaf_pct"       1..100: a wave switches from node steps to leaf steps once this share of its busy lanes
  *                    holds a leaf; 100 = descend until every lane does.
- *   "block_threads"  64, 128 or 256.
+ *   "block_threads"  64 (default), 128 or 256.
  *   "waves_per_cu"   0..64: cap on resident waves per CU, held by sizing the traversal stack in LDS (default 0 =
  *                    whatever registers and the tree depth allow).
  *   "extra_stack"    diagnostic: extra traversal-stack entries per lane (lowers occupancy).

@@ -298,7 +298,7 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
         dict(image_width=W, centre_first=1),
         dict(image_width=W, feedback=1),
         dict(image_width=0, feedback=1),
-        dict(image_width=W, feedback=1, block_threads=64),
+        dict(image_width=W, feedback=1, block_threads=256),
         dict(image_width=W, feedback=1, block_threads=128, feedback_radius=0),
         dict(image_width=W, feedback=1, feedback_radius=3, feedback_share=128),
         dict(image_width=0, feedback=1, feedback_radius=2, feedback_share=10),
@@ -307,7 +307,7 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
         dict(image_width=W, leaf_pct=37, block_threads=128, width=4),
         dict(image_width=W, quantized=0, feedback=1, width=4),
     ]
-    defaults = dict(width=2, quantized=1, block_threads=256, image_width=0, leaf_pct=50,
+    defaults = dict(width=2, quantized=1, block_threads=64, image_width=0, leaf_pct=50,
                     centre_first=1, feedback=0, feedback_radius=1, feedback_share=96)
     for cfg in settings:
         for k, v in {**defaults, **cfg}.items():

@@ -37,7 +37,7 @@ n = len(rays)
 d_rays = torch.from_numpy(rays).cuda()
 d_hits = torch.empty((n, 16 if a.out == "full" else 4), dtype=torch.float32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
-DEFAULTS = {"width": 2, "quantized": 1, "block_threads": 256, "image_width": 0, "extra_stack": 0, "leaf_pct": 50, "centre_first": 1, "feedback": 0, "waves_per_cu": 0, "feedback_radius": 1, "feedback_share": 96}
+DEFAULTS = {"width": 2, "quantized": 1, "block_threads": 64, "image_width": 0, "extra_stack": 0, "leaf_pct": 50, "centre_first": 1, "feedback": 0, "waves_per_cu": 0, "feedback_radius": 1, "feedback_share": 96}
 
 
 def apply(cfg):
