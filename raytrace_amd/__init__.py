@@ -89,6 +89,7 @@ def _load():
         "rt_scene_set_param": (i32, [vp, C.c_char_p, i32]),
         "ray_scene_intersection": (i32, [vp, sz, vp, vp]),
         "rt_intersect_async": (i32, [vp, vp, sz, vp, vp, vp]),
+        "rt_intersect_static": (i32, [vp, vp, sz, vp, vp, vp]),
         "rt_trace_pass": (i32, [vp, vp, vp, vp, sz, C.POINTER(C.c_float), u32, vp]),
         "rt_trace_primary": (i32, [vp, i32, i32, C.POINTER(C.c_float), vp, vp, vp]),
         "rt_scene_count_fetches": (i32, [vp, vp, sz, sz, C.POINTER(u64), vp]),
@@ -259,6 +260,11 @@ class Scene:
     def intersect_async(self, rays_ptr, n, hits_ptr=None, hits16_ptr=None, stream=0):
         _check(lib.rt_intersect_async(self._h, _ptr(rays_ptr), n, _ptr(hits_ptr), _ptr(hits16_ptr),
                                       C.c_void_p(stream) if stream else None))
+
+    def intersect_static(self, rays_ptr, n, hits_ptr=None, hits16_ptr=None, stream=0):
+        """rt_intersect_async's allocation-free twin (fixed schedule tables inside the library)."""
+        _check(lib.rt_intersect_static(self._h, _ptr(rays_ptr), n, _ptr(hits_ptr), _ptr(hits16_ptr),
+                                       C.c_void_p(stream) if stream else None))
 
     def trace_primary(self, width, height, origin, hits_ptr=None, hits16_ptr=None, stream=0):
         o = (C.c_float * 3)(*[float(x) for x in origin])

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <algorithm>
 #include <string>
@@ -66,6 +67,42 @@ int Upload(T **dst, const void *src, size_t bytes)
 
 constexpr uint32_t kFeedbackMaxRays = 1u << 30;  // single-launch calls only
 constexpr int kStatShards = 64;          // instrumented build: counter shards, 16 uint64 (one line) each
+
+// ---- fixed device memory of the allocation-free entry point (rt_intersect_static) ----------------------
+// The cost-feedback schedule needs two tables per launch shape: the per-unit cost the trace kernel records
+// and the dispatch order the sort kernel derives from it.  rt_intersect_async keeps them in hipMalloc'd
+// buffers owned by the scene; callers that must not allocate get them from this array instead, one copy
+// per GPU the library runs on, held until the process ends: 2 MiB = 2^18 cost words + 2^18 order words,
+// enough for 2^18 wave-sized work units = 16 Mi rays per call.
+constexpr uint32_t kStaticMaxUnits = 1u << 18;
+constexpr size_t kStaticMaxRays = static_cast<size_t>(kStaticMaxUnits) * 64u;
+static __device__ __align__(256) uint32_t scratch[2u * kStaticMaxUnits];
+
+// In host code the name `scratch` is only a handle; the array's address on a given GPU comes from
+// hipGetSymbolAddress with that GPU current, once per device, and is what every launch and memset uses.
+constexpr int kMaxDevices = 64;
+struct StaticState {
+  uint32_t *ptr = nullptr;      // device address of `scratch` on this GPU
+  uint32_t ntasks = 0, n = 0, img_w = 0;   // shape the tables currently describe
+  bool order_valid = false;     // the order half holds a schedule for that shape
+};
+StaticState g_static[kMaxDevices];
+std::mutex g_static_mutex;   // guards the one-time address lookup only
+
+// Caller holds the device current.
+int StaticScratch(int device, StaticState **out)
+{
+  if (device < 0 || device >= kMaxDevices) return Fail(RT_ERR_DEVICE, "device ordinal beyond the allocation-free entry point's table");
+  StaticState &st = g_static[device];
+  std::lock_guard<std::mutex> lock(g_static_mutex);
+  if (!st.ptr) {
+    void *p = nullptr;
+    RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    st.ptr = static_cast<uint32_t *>(p);
+  }
+  *out = &st;
+  return RT_OK;
+}
 
 }  // namespace
 
@@ -186,7 +223,8 @@ int ResetFeedback(const rt_scene *s)
 }
 
 // Enqueues one launch over at most 2^30 rays.
-int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStream_t stream)
+// Work units of a launch over a.n rays: 8x8 pixel tiles when the rays are declared an image, else runs of 64.
+void SetShape(const rt_scene *s, rt::KernelArgs &a, int mode)
 {
   const uint32_t width_hint = mode == rt::kModePrimary ? a.img_w : static_cast<uint32_t>(s->image_width);
   a.img_w = a.img_h = 0;
@@ -195,11 +233,16 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     a.img_w = width_hint;
     a.img_h = a.n / a.img_w;
     a.ntasks = ((a.img_w + 7u) / 8u) * ((a.img_h + 7u) / 8u);
-    if (s->centre_first) {
-      int rc = EnsureOrder(s, a.img_w, a.img_h);
-      if (rc != RT_OK) return rc;
-      a.order = s->d_order;
-    }
+  }
+}
+
+int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStream_t stream)
+{
+  SetShape(s, a, mode);
+  if (a.img_w && s->centre_first) {
+    int rc = EnsureOrder(s, a.img_w, a.img_h);
+    if (rc != RT_OK) return rc;
+    a.order = s->d_order;
   }
   const uint32_t block = static_cast<uint32_t>(s->block_threads), wpb = block / 64u;
   if (s->waves_per_cu > 0) {
@@ -467,6 +510,10 @@ int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, s
   int rc = guard.ok ? RT_OK : Fail(RT_ERR_DEVICE, "hipSetDevice failed");
   hipDeviceProp_t prop;
   if (rc == RT_OK && hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cu = prop.multiProcessorCount;
+  if (rc == RT_OK) {   // look the fixed tables of rt_intersect_static up now, so that its calls have nothing left to set up
+    StaticState *st = nullptr;
+    rc = StaticScratch(device, &st);
+  }
   if (rc == RT_OK) rc = Upload(&s->d_nodes2, s->flat.nodes2.data(), s->flat.nodes2.size() * sizeof(rt::GpuNode2));
   if (rc == RT_OK) rc = Upload(&s->d_nodes4, s->flat.nodes4.data(), s->flat.nodes4.size() * sizeof(rt::GpuNode4));
   if (rc == RT_OK) rc = Upload(&s->d_nodesq2, s->flat.nodesq2.data(), s->flat.nodesq2.size() * sizeof(rt::GpuChildQ));
@@ -583,6 +630,58 @@ int rt_intersect_async(const rt_scene *s, const void *rays_dev, size_t n, void *
     int rc = Enqueue(s, a, rt::kModeIntersect, false, static_cast<hipStream_t>(stream));
     if (rc != RT_OK) return rc;
   }
+  return RT_OK;
+}
+
+int rt_intersect_static(const rt_scene *s, const void *rays_dev, size_t n, void *hits_dev, void *hits16_dev, void *stream)
+{
+  if (!s) return Fail(RT_ERR_INVALID, "null scene");
+  if (s->device == RT_DEVICE_NONE) return Fail(RT_ERR_DEVICE, "scene was created without a device");
+  if (n == 0) return RT_OK;
+  if (!rays_dev || (!hits_dev && !hits16_dev)) return Fail(RT_ERR_INVALID, "null ray or hit buffer");
+  if (n > kStaticMaxRays)
+    return Fail(RT_ERR_INVALID, "rt_intersect_static takes at most " + std::to_string(kStaticMaxRays) + " rays per call (" +
+                                    std::to_string(n) + " given); split the call or use rt_intersect_async");
+  DeviceGuard guard(s->device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  StaticState *st = nullptr;
+  int rc = StaticScratch(s->device, &st);
+  if (rc != RT_OK) return rc;
+  hipStream_t q = static_cast<hipStream_t>(stream);
+  rt::KernelArgs a;
+  FillArgs(s, a);
+  a.rays = static_cast<const rt_ray_isect *>(rays_dev);
+  a.hits = static_cast<rt_ray_isect *>(hits_dev);
+  a.hits16 = static_cast<rt_hit16 *>(hits16_dev);
+  a.n = static_cast<uint32_t>(n);
+  SetShape(s, a, rt::kModeIntersect);
+  if (a.ntasks > kStaticMaxUnits)   // an image hint can round tiles up past n / 64
+    return Fail(RT_ERR_INVALID, "rt_intersect_static: " + std::to_string(a.ntasks) + " work units exceed the fixed tables (" +
+                                    std::to_string(kStaticMaxUnits) + ")");
+  if (static_cast<size_t>(a.stack_entries) * 4u * 64u > 160u * 1024u)
+    return Fail(RT_ERR_INVALID, "bvh too deep for the LDS traversal stack");
+  uint32_t *cost = st->ptr, *order = st->ptr + kStaticMaxUnits;
+  const size_t padded = static_cast<size_t>(rt::BuildOrderKeysPerThread(a.ntasks)) * 512u;   // <= kStaticMaxUnits
+  if (st->ntasks != a.ntasks || st->n != a.n || st->img_w != a.img_w) {
+    // the array keeps the previous call's contents: a new shape starts from zero costs and no order
+    RT_HIP(hipMemsetAsync(cost, 0, padded * sizeof(uint32_t), q));
+    st->ntasks = a.ntasks; st->n = a.n; st->img_w = a.img_w;
+    st->order_valid = false;
+  }
+  a.order = st->order_valid ? order : nullptr;
+  a.unit_cost = cost;
+  a.cost_radius = static_cast<uint32_t>(s->feedback_radius);
+  a.cost_share = static_cast<uint32_t>(s->feedback_share);
+  hipError_t e = rt::LaunchClosestHit(a, s->width, s->quant != 0, rt::kModeIntersect, false, a.ntasks, 64u, q);
+  if (e != hipSuccess) return FailHip(e, "kernel launch failed");
+  // same stream, after the trace: turns this call's costs into the next call's order and zeroes the cost half
+  e = rt::LaunchBuildOrder(cost, a.ntasks, order, q);
+  if (e != hipSuccess) {
+    st->order_valid = false;
+    st->ntasks = 0;   // the cost half may be dirty: start over next time
+    return FailHip(e, "order kernel launch failed");
+  }
+  st->order_valid = true;
   return RT_OK;
 }
 
