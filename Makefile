@@ -12,7 +12,7 @@ BUILD = build
 # stay correctly rounded.
 HOSTFLAGS = -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
 HIPFLAGS = -std=c++17 -O3 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-           -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -Wall -Wno-unused-parameter -Iinclude
+           -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -Wall -Wno-unused-parameter -Iinclude $(EXTRA_HIPFLAGS)
 
 HOST_SRCS = obj_loader centroid_bvh sah_bvh raygen flatten framebuffer
 HIP_SRCS = trace_kernels capi

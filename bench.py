@@ -84,6 +84,8 @@ def parse():
                          "through, so that no step repeats the previous step's rays")
     ap.add_argument("--feedback-radius", type=int, default=-1, help="-1 = library default")
     ap.add_argument("--feedback-share", type=int, default=-1, help="-1 = library default")
+    ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra rt_scene_set_param settings (repeatable), applied last")
     ap.add_argument("--feedback", type=int, default=1,
                     help="1: each launch starts its work units costliest-first, by the costs measured two launches earlier")
     return ap.parse_args()
@@ -152,6 +154,9 @@ def main():
         scene.set_param("feedback_share", a.feedback_share)
     if a.waves_per_cu >= 0:
         scene.set_param("waves_per_cu", a.waves_per_cu)
+    for kv in a.param:
+        k, v = kv.split("=")
+        scene.set_param(k, int(v))
     info = scene.info()
     box = bvh.root_box
 

@@ -125,7 +125,12 @@ int rt_scene_info(const rt_scene *s, uint64_t info[8]);
  *   "block_threads"  64 (default), 128 or 256.
  *   "waves_per_cu"   0..64: cap on resident waves per CU, held by sizing the traversal stack in LDS (default 0 =
  *                    whatever registers and the tree depth allow).
- *   "extra_stack"    diagnostic: extra traversal-stack entries per lane (lowers occupancy).
+ *   "lds_stack"      8..32 (default 12): traversal-stack entries per lane kept in LDS (8 bytes each); deeper entries
+ *                    spill to the lane's private memory.  Rays of a framed object rarely go deeper than 11.
+ *   "persistent"     1: instead of one wave per work unit, "persistent_waves" (1..64, default 24) waves per CU
+ *                    stay resident and take units from a global cursor, one wave-level atomic per unit, in
+ *                    dispatch order.  0 (default): the hardware dispatcher hands units out (measured faster).
+ *   "extra_stack"    diagnostic: extra LDS traversal-stack entries per lane (lowers occupancy).
  * Calls on one scene must not overlap in time from different host threads (the scene caches launch state);
  * the launches themselves may go to any streams. */
 int rt_scene_set_param(rt_scene *s, const char *key, int value);
@@ -177,11 +182,11 @@ int rt_trace_pass(const rt_scene *scene, const void *rays_in_dev, void *rays_out
                   const float cam[16], unsigned trace_operation, void *stream);
 
 /* Mean records fetched per ray by the traversal, counted on the host over rays
- * 0, stride, 2*stride, ... : counts[0..4] = {node records, triangle records, non-empty
- * leaves, rays that hit, rays counted}.  per_ray (nullable, 2 x rays-counted uint32) receives each counted
+ * 0, stride, 2*stride, ... : counts[0..5] = {node records, triangle records, non-empty
+ * leaves, rays that hit, rays counted, deepest traversal stack (entries) of any counted ray}.  per_ray (nullable, 2 x rays-counted uint32) receives each counted
  * ray's own {node records, triangle records}.  A measurement aid; computes no hits. */
 int rt_scene_count_fetches(const rt_scene *s, const rt_ray_isect *rays_host, size_t n, size_t stride,
-                           uint64_t counts[5], uint32_t *per_ray);
+                           uint64_t counts[6], uint32_t *per_ray);
 /* Planning aid: a host-side lockstep model of one 64-lane wave running the traversal (a phase lasts as
  * long as its slowest lane).  Samples `max_waves` waves (0 = all) over the ray stream and returns
  * out[0..9] = {waves, rays, wave node steps, useful lane node steps, wave triangle steps, useful lane
@@ -193,8 +198,9 @@ int rt_scene_count_fetches(const rt_scene *s, const rt_ray_isect *rays_host, siz
 int rt_scene_wave_model(const rt_scene *s, const rt_ray_isect *rays_host, size_t n, unsigned image_width, unsigned refill,
                         size_t max_waves, int policy, uint64_t out[12]);
 /* The same counters taken on the device by an instrumented build of the kernel over all n
- * rays (device pointer): counts[0..3] as above, counts[4] = n. */
-int rt_scene_count_fetches_device(const rt_scene *s, const void *rays_dev, size_t n, uint64_t counts[5]);
+ * rays (device pointer): counts[0..3] as above, counts[4] = n, counts[5] = the deepest traversal stack
+ * (entries) any ray reached. */
+int rt_scene_count_fetches_device(const rt_scene *s, const void *rays_dev, size_t n, uint64_t counts[6]);
 
 /* Diagnostic: runs the instrumented kernel once over n device-resident rays and returns, per wave of
  * 64 rays (or per 8x8 tile with the image hint), records[4*w..4*w+3] = {start, end in 100 MHz ticks,

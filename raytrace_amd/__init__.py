@@ -18,7 +18,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtamd.so")
+LIB_PATH = os.environ.get("RT_LIB") or os.path.join(_HERE, "librtamd.so")   # RT_LIB: an A/B build of the same library
 REPO_ROOT = os.path.dirname(_HERE)
 MODELS_DIR = os.path.join(REPO_ROOT, "assets", "models")
 
@@ -278,10 +278,10 @@ class Scene:
 
     def count_fetches(self, rays, stride=1, per_ray=False):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, RAY_FLOATS)
-        v = (C.c_uint64 * 5)()
+        v = (C.c_uint64 * 6)()
         pr = np.zeros(((len(rays) + stride - 1) // stride, 2), np.uint32) if per_ray else None
         _check(lib.rt_scene_count_fetches(self._h, _ptr(rays), len(rays), stride, v, _ptr(pr)))
-        out = dict(zip(["nodes", "tris", "leaves", "rays_hit", "rays"], [int(x) for x in v]))
+        out = dict(zip(["nodes", "tris", "leaves", "rays_hit", "rays", "max_stack"], [int(x) for x in v]))
         return (out, pr) if per_ray else out
 
     def wave_model(self, rays, image_width=0, refill=0, max_waves=0, policy=0):
@@ -301,9 +301,9 @@ class Scene:
         return out[out[:, 1] != 0]
 
     def count_fetches_device(self, rays_ptr, n):
-        v = (C.c_uint64 * 5)()
+        v = (C.c_uint64 * 6)()
         _check(lib.rt_scene_count_fetches_device(self._h, _ptr(rays_ptr), n, v))
-        return dict(zip(["nodes", "tris", "leaves", "rays_hit", "rays"], [int(x) for x in v]))
+        return dict(zip(["nodes", "tris", "leaves", "rays_hit", "rays", "max_stack"], [int(x) for x in v]))
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

@@ -67,6 +67,7 @@ int Upload(T **dst, const void *src, size_t bytes)
 
 constexpr uint32_t kFeedbackMaxRays = 1u << 30;  // single-launch calls only
 constexpr int kStatShards = 64;          // instrumented build: counter shards, 16 uint64 (one line) each
+constexpr uint32_t kCursorSlots = 64, kCursorStride = 32;   // persistent launches: cursor words, one line apart
 
 // ---- fixed device memory of the allocation-free entry point (rt_intersect_static) ----------------------
 // The cost-feedback schedule needs two tables per launch shape: the per-unit cost the trace kernel records
@@ -132,6 +133,12 @@ struct rt_scene {
   mutable hipStream_t side = nullptr;                       // the order-building kernel runs here, beside the next trace
   mutable hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_sort[2] = {nullptr, nullptr};
   int waves_per_cu = 0;          // optional resident-wave cap per CU, held through the LDS stack size (0 = none)
+  int prio_permille = 0;         // with a cost-sorted order: this share (1/1000) of the leading dispatch slots runs at raised priority
+  int lds_stack = 12;            // traversal-stack entries per lane kept in LDS; deeper entries spill to private memory
+  int persistent = 0;            // 1: a fixed grid of waves pulls work units from a global cursor (one atomic per unit)
+  int persistent_waves = 24;     // ... this many waves per CU
+  uint32_t *d_cursor = nullptr;  // kCursorSlots cursors, one 128-byte line each, used round-robin by consecutive launches
+  mutable uint32_t next_cursor = 0;
   int feedback_share = 96;       // ... scaled by this many 128ths
   int feedback_radius = 1;       // a unit's measured cost also counts for its neighbours this many units away
   int leaf_pct = 50;             // node/leaf step scheduling threshold (percent of busy lanes parked at a leaf)
@@ -165,8 +172,8 @@ void FillArgs(const rt_scene *s, rt::KernelArgs &a)
   a.mats = s->d_mats;
   a.nnormals = static_cast<uint32_t>(s->nnormals);
   a.nmats = static_cast<uint32_t>(s->nmats);
-  // at least 16 entries per lane: the output stage exchanges the wave's 64 x 64-byte records through the stack
-  a.stack_entries = static_cast<uint32_t>(std::max(16, (s->width == 4 ? s->flat.stack4 : s->flat.stack2) + s->extra_stack));
+  // the LDS part of the stack; the output stage also exchanges the wave's 64 x 64-byte records through it
+  a.stack_entries = std::max(rt::kMinLdsEntries, static_cast<uint32_t>(s->lds_stack + s->extra_stack));
   a.scale = s->flat.scale;
   a.leaf_pct = static_cast<uint32_t>(s->leaf_pct);
   a.stats = s->d_stats;
@@ -223,6 +230,20 @@ int ResetFeedback(const rt_scene *s)
 }
 
 // Enqueues one launch over at most 2^30 rays.
+// The traversal stack must cover the tree's worst case (LDS part + private part), and the LDS part of one
+// workgroup must fit a CU.
+int CheckStack(const rt_scene *s, const rt::KernelArgs &a, uint32_t block)
+{
+  const uint32_t need = static_cast<uint32_t>(s->width == 4 ? s->flat.stack4 : s->flat.stack2);
+  if (need > a.stack_entries + rt::kDeepEntries)
+    return Fail(RT_ERR_INVALID, "bvh too deep for the traversal stack: " + std::to_string(need) + " entries needed, " +
+                                    std::to_string(a.stack_entries + rt::kDeepEntries) + " available");
+  if (static_cast<size_t>(a.stack_entries) * 8u * block > 160u * 1024u)
+    return Fail(RT_ERR_INVALID, "traversal stack of " + std::to_string(a.stack_entries) + " LDS entries x " + std::to_string(block) +
+                                    " threads exceeds a CU's 160 KB of LDS (lower waves_per_cu / lds_stack / extra_stack)");
+  return RT_OK;
+}
+
 // Work units of a launch over a.n rays: 8x8 pixel tiles when the rays are declared an image, else runs of 64.
 void SetShape(const rt_scene *s, rt::KernelArgs &a, int mode)
 {
@@ -250,10 +271,16 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     // allocation of the kernel variant is.  Measured: 24 gains 3 % on 1080p frames and loses 9-14 % on 4K frames
     // and incoherent rays, so it is off unless asked for.
     const uint32_t groups = std::max(1u, static_cast<uint32_t>(s->waves_per_cu) / wpb);
-    const uint32_t min_bytes = 160u * 1024u / (groups + 1u) + 1u, entry_bytes = 4u * block;
+    const uint32_t min_bytes = 160u * 1024u / (groups + 1u) + 1u, entry_bytes = 8u * block;
     a.stack_entries = std::max(a.stack_entries, (min_bytes + entry_bytes - 1u) / entry_bytes);
   }
-  const uint32_t grid = (a.ntasks + wpb - 1u) / wpb;   // one wave per work unit
+  uint32_t grid = (a.ntasks + wpb - 1u) / wpb;   // one wave per work unit
+  if (s->persistent && !count) {
+    // a fixed number of resident waves; each takes units from a cursor word that this launch's stream zeroes first
+    grid = std::min(grid, static_cast<uint32_t>(s->num_cu) * std::max(1u, static_cast<uint32_t>(s->persistent_waves) / wpb));
+    a.cursor = s->d_cursor + (s->next_cursor++ % kCursorSlots) * kCursorStride;
+    RT_HIP(hipMemsetAsync(a.cursor, 0, sizeof(uint32_t), stream));
+  }
   int fb_slot = -1;
   if (s->feedback == 1 && !count && a.n < kFeedbackMaxRays) {
     if (s->fb_ntasks != a.ntasks || s->fb_n != a.n || s->fb_img_w != a.img_w) {  // new shape: start over
@@ -281,6 +308,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
       RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[fb_slot], 0));
       a.order = s->d_fb_order[fb_slot];
     }
+    if (a.order) a.prio_slots = static_cast<uint32_t>(static_cast<uint64_t>(a.ntasks) * static_cast<uint32_t>(s->prio_permille) / 1000u);
     a.unit_cost = s->d_fb_cost[fb_slot];
     a.cost_radius = static_cast<uint32_t>(s->feedback_radius);
     a.cost_share = static_cast<uint32_t>(s->feedback_share);
@@ -291,8 +319,10 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[newest], 0));
     a.order = s->d_fb_order[newest];
   }
-  if (static_cast<size_t>(a.stack_entries) * 1024u > 160u * 1024u)
-    return Fail(RT_ERR_INVALID, "bvh too deep for the LDS traversal stack");
+  {
+    int rc = CheckStack(s, a, block);
+    if (rc != RT_OK) return rc;
+  }
   {
     hipError_t e_ = rt::LaunchClosestHit(a, s->width, s->quant != 0, mode, count, grid, block, stream);
     if (e_ != hipSuccess)
@@ -524,6 +554,7 @@ int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, s
   if (rc == RT_OK) rc = Upload(&s->d_normals, normals, nnormals * sizeof(rt_float4));
   if (rc == RT_OK) rc = Upload(&s->d_mats, materials, nmats * sizeof(rt_material));
   if (rc == RT_OK) rc = Upload(&s->d_stats, nullptr, kStatShards * 16 * sizeof(unsigned long long));
+  if (rc == RT_OK) rc = Upload(&s->d_cursor, nullptr, kCursorSlots * kCursorStride * sizeof(uint32_t));
   if (rc != RT_OK) {
     std::string keep = g_error;
     rt_scene_destroy(s);
@@ -544,7 +575,7 @@ void rt_scene_destroy(rt_scene *s)
   DeviceGuard guard(s->device);
   (void)hipFree(s->d_nodes2); (void)hipFree(s->d_nodes4); (void)hipFree(s->d_nodesq2); (void)hipFree(s->d_nodesq4); (void)hipFree(s->d_tris);
   (void)hipFree(s->d_verts); (void)hipFree(s->d_faces); (void)hipFree(s->d_normals); (void)hipFree(s->d_mats);
-  (void)hipFree(s->d_stats); (void)hipFree(s->d_order); (void)ResetFeedback(s);
+  (void)hipFree(s->d_stats); (void)hipFree(s->d_cursor); (void)hipFree(s->d_order); (void)ResetFeedback(s);
   if (s->side) {
     (void)hipStreamDestroy(s->side);
     for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(s->ev_main[k]); (void)hipEventDestroy(s->ev_sort[k]); }
@@ -593,6 +624,18 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "leaf_pct") {
     if (value < 1 || value > 100) return Fail(RT_ERR_INVALID, "leaf_pct must be in 1..100");
     s->leaf_pct = value;
+  } else if (k == "prio_permille") {
+    if (value < 0 || value > 1000) return Fail(RT_ERR_INVALID, "prio_permille must be in 0..1000");
+    s->prio_permille = value;
+  } else if (k == "lds_stack") {
+    if (value < static_cast<int>(rt::kMinLdsEntries) || value > 32) return Fail(RT_ERR_INVALID, "lds_stack must be in 8..32");
+    s->lds_stack = value;
+  } else if (k == "persistent") {
+    if (value < 0 || value > 1) return Fail(RT_ERR_INVALID, "persistent must be 0 or 1");
+    s->persistent = value;
+  } else if (k == "persistent_waves") {
+    if (value < 1 || value > 64) return Fail(RT_ERR_INVALID, "persistent_waves must be in 1..64");
+    s->persistent_waves = value;
   } else if (k == "extra_stack") {
     if (value < 0 || value > 128) return Fail(RT_ERR_INVALID, "extra_stack out of range");
     s->extra_stack = value;
@@ -658,8 +701,8 @@ int rt_intersect_static(const rt_scene *s, const void *rays_dev, size_t n, void 
   if (a.ntasks > kStaticMaxUnits)   // an image hint can round tiles up past n / 64
     return Fail(RT_ERR_INVALID, "rt_intersect_static: " + std::to_string(a.ntasks) + " work units exceed the fixed tables (" +
                                     std::to_string(kStaticMaxUnits) + ")");
-  if (static_cast<size_t>(a.stack_entries) * 4u * 64u > 160u * 1024u)
-    return Fail(RT_ERR_INVALID, "bvh too deep for the LDS traversal stack");
+  rc = CheckStack(s, a, 64u);
+  if (rc != RT_OK) return rc;
   uint32_t *cost = st->ptr, *order = st->ptr + kStaticMaxUnits;
   const size_t padded = static_cast<size_t>(rt::BuildOrderKeysPerThread(a.ntasks)) * 512u;   // <= kStaticMaxUnits
   if (st->ntasks != a.ntasks || st->n != a.n || st->img_w != a.img_w) {
@@ -765,13 +808,14 @@ int rt_trace_pass(const rt_scene *s, const void *rays_in_dev, void *rays_out_dev
 }
 
 int rt_scene_count_fetches(const rt_scene *s, const rt_ray_isect *rays_host, size_t n, size_t stride,
-                           uint64_t counts[5], uint32_t *per_ray)
+                           uint64_t counts[6], uint32_t *per_ray)
 {
   if (!s || !rays_host || !counts) return Fail(RT_ERR_INVALID, "null argument");
   if (stride == 0) stride = 1;
   rt::FetchCounts fc = rt::CountFetches(s->flat, s->width, s->quant != 0, rays_host, n, stride, per_ray);
   counts[0] = fc.nodes; counts[1] = fc.tris; counts[2] = fc.leaves; counts[3] = fc.rays_hit;
   counts[4] = (n + stride - 1) / stride;
+  counts[5] = fc.max_stack;
   return RT_OK;
 }
 
@@ -786,7 +830,7 @@ int rt_scene_wave_model(const rt_scene *s, const rt_ray_isect *rays_host, size_t
   return RT_OK;
 }
 
-int rt_scene_count_fetches_device(const rt_scene *s, const void *rays_dev, size_t n, uint64_t counts[5])
+int rt_scene_count_fetches_device(const rt_scene *s, const void *rays_dev, size_t n, uint64_t counts[6])
 {
   if (!s || !rays_dev || !counts) return Fail(RT_ERR_INVALID, "null argument");
   if (s->device == RT_DEVICE_NONE) return Fail(RT_ERR_DEVICE, "scene was created without a device");
@@ -810,6 +854,8 @@ int rt_scene_count_fetches_device(const rt_scene *s, const void *rays_dev, size_
     for (int sh = 0; sh < kStatShards; ++sh) counts[i] += h[sh * 16 + i];
   }
   counts[4] = n;
+  counts[5] = 0;
+  for (int sh = 0; sh < kStatShards; ++sh) counts[5] = std::max<uint64_t>(counts[5], h[sh * 16 + 4]);
   return RT_OK;
 }
 

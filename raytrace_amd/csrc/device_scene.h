@@ -16,6 +16,8 @@ constexpr int kModeIntersect = 0;  // rays used as given (ray_scene_intersection
 constexpr int kFbBuckets = 16;     // cost bins of the launch-to-launch feedback schedule
 constexpr int kModeTrace = 1;      // full `trace` step: camera / reflection setup + pixel
 constexpr int kModePrimary = 2;    // rays of the reference's primary table, generated in the kernel (no ray array)
+constexpr uint32_t kDeepEntries = 56;   // traversal-stack entries per lane beyond the LDS part, in private memory
+constexpr uint32_t kMinLdsEntries = 8;  // the output stage exchanges 64 x 64-byte records through the LDS part
 
 struct KernelArgs {
   const float4 *nodes;        // float boxes: 4 (two-wide) or 8 (four-wide) float4 per record;
@@ -33,15 +35,17 @@ struct KernelArgs {
   // Cost feedback between consecutive launches of the same shape (nullable): every wave stores the number of
   // traversal iterations its work unit needed; a small sort kernel turns that into the next launch's order.
   uint32_t *unit_cost;
+  uint32_t *cursor;           // nullable: persistent launch, waves take dispatch-order positions from this counter
   unsigned long long *stats;  // instrumented build only: nodes, tris, leaves, rays hit
   unsigned long long *timeline;  // instrumented build only, nullable: per wave {start, end (100 MHz ticks), hw id, xcc id}
   uint32_t n;
   uint32_t ntasks;            // wave-sized work items: ceil(n/64), or the number of 8x8 tiles
+  uint32_t prio_slots;        // the first this-many dispatch slots run at raised issue priority (0 = none)
   uint32_t cost_radius;       // a unit's cost is also recorded for its neighbours within this many units (<= 3)
   uint32_t cost_share;        // ... scaled by this many 128ths
   uint32_t nnormals;
   uint32_t nmats;
-  uint32_t stack_entries;     // LDS stack entries per lane
+  uint32_t stack_entries;     // traversal-stack entries per lane held in LDS (8 bytes each), >= kMinLdsEntries
   uint32_t op;                // kModeTrace: 0 = camera transform, 1 = reflect
   uint32_t img_w;             // > 0: rays are a row-major img_w x img_h image, walked in 8x8 pixel tiles per wave
   uint32_t img_h;

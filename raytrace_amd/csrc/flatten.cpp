@@ -144,15 +144,40 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
   out->depth2 = max_depth;
   out->stack2 = max_depth + 1;
 
-  // ---- BVH4: pull grandchildren up, largest box first -----------------------------
-  // Each BVH4 node is rooted at a BVH2 inner node; the set {child0, child1} is widened by
-  // replacing its largest inner member with that member's two children until it holds four
-  // entries or only leaves.
+  // ---- BVH4: pull grandchildren up, largest box first; then open leaves into the slots left over ----------
+  // Each BVH4 node is rooted at a BVH2 inner node; the set {child0, child1} is widened by replacing its largest
+  // inner member with that member's two children until it holds four entries or only leaves.  Slots still free
+  // after that (a quarter of all slots on the benchmark meshes) would be tested by every visiting ray for
+  // nothing, so they are given to the node's leaves: a leaf of 2..4 triangles is split into two runs with their
+  // own, tighter boxes (the two-way partition of its triangles with the least summed area x count; a leaf's
+  // records are reordered to make both runs contiguous).  Same triangles under the same node, same node count,
+  // fewer triangle tests per ray.
   {
+    struct Kid {
+      bool inner;
+      uint32_t node;        // inner: reference-node index
+      uint32_t first, cnt;  // leaf: run of triangle records
+      rt_aabb box;
+    };
+    auto kid_of = [&](uint32_t node) {
+      Kid k{};
+      k.inner = nodes[node].type == RT_BVH_INNER;
+      k.node = node;
+      k.box = nodes[node].aabb;
+      if (!k.inner) { k.first = (leaf_ref[node] & ~kLeafBit) >> 3; k.cnt = leaf_ref[node] & 7u; }
+      return k;
+    };
+    auto tri_box = [&](uint32_t rec, rt_aabb *b, bool init) {
+      rt_face const &f = faces[out->tris[rec].id];
+      for (int c = 0; c < 3; ++c) {
+        rt_vec3 const &v = verts[f.s[c]];
+        if (init && c == 0) { b->a = v; b->b = v; continue; }
+        b->a.x = std::min(b->a.x, v.x); b->a.y = std::min(b->a.y, v.y); b->a.z = std::min(b->a.z, v.z);
+        b->b.x = std::max(b->b.x, v.x); b->b.y = std::max(b->b.y, v.y); b->b.z = std::max(b->b.z, v.z);
+      }
+    };
     std::vector<uint32_t> id4(nnodes, 0xFFFFFFFFu);
-    struct Pending { uint32_t root; int depth; };
-    std::vector<Pending> q{{0u, 1}};
-    std::vector<std::array<uint32_t, 4>> kids;
+    std::vector<std::array<Kid, 4>> kids;
     std::vector<int> nk;
     id4[0] = 0;
     std::vector<uint32_t> roots{0u};
@@ -161,31 +186,71 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
     for (size_t qi = 0; qi < roots.size(); ++qi) {  // breadth-first numbering keeps the top levels dense
       const uint32_t r = roots[qi];
       max4 = std::max(max4, depths[qi]);
-      uint32_t set[4] = {nodes[r].node.inner.children_index[0], nodes[r].node.inner.children_index[1], 0, 0};
+      std::array<Kid, 4> set{};
+      set[0] = kid_of(nodes[r].node.inner.children_index[0]);
+      set[1] = kid_of(nodes[r].node.inner.children_index[1]);
       int n = 2;
       while (n < 4) {
         int pick = -1;
         float best = -1.f;
         for (int k = 0; k < n; ++k)
-          if (nodes[set[k]].type == RT_BVH_INNER) {
-            float a = Area(nodes[set[k]].aabb);
+          if (set[k].inner) {
+            float a = Area(set[k].box);
             if (a > best) { best = a; pick = k; }
           }
         if (pick < 0) break;
-        const uint32_t p = set[pick];
-        set[pick] = nodes[p].node.inner.children_index[0];
-        set[n++] = nodes[p].node.inner.children_index[1];
+        const uint32_t p = set[pick].node;
+        set[pick] = kid_of(nodes[p].node.inner.children_index[0]);
+        set[n++] = kid_of(nodes[p].node.inner.children_index[1]);
       }
-      std::array<uint32_t, 4> ks{};
-      for (int k = 0; k < n; ++k) {
-        ks[k] = set[k];
-        if (nodes[set[k]].type == RT_BVH_INNER) {
-          id4[set[k]] = static_cast<uint32_t>(roots.size());
-          roots.push_back(set[k]);
+      while (n < 4) {
+        int pick = -1;
+        float best = -1.f;
+        for (int k = 0; k < n; ++k)
+          if (!set[k].inner && set[k].cnt >= 2) {
+            float a = Area(set[k].box) * static_cast<float>(set[k].cnt);
+            if (a > best) { best = a; pick = k; }
+          }
+        if (pick < 0) break;
+        const Kid leaf = set[pick];
+        // every two-way partition of the <= 4 records: bit j of `mask` set = record j goes to the second run
+        uint32_t best_mask = 0;
+        float best_cost = kFltMax;
+        for (uint32_t mask = 1; mask + 1 < (1u << leaf.cnt); ++mask) {
+          if (mask & 1u) continue;  // record 0 stays in the first run: each partition is seen once
+          rt_aabb ba{}, bb{};
+          uint32_t na = 0, nb = 0;
+          for (uint32_t j = 0; j < leaf.cnt; ++j) {
+            if (mask >> j & 1u) tri_box(leaf.first + j, &bb, nb++ == 0);
+            else tri_box(leaf.first + j, &ba, na++ == 0);
+          }
+          const float cost = Area(ba) * static_cast<float>(na) + Area(bb) * static_cast<float>(nb);
+          if (cost < best_cost) { best_cost = cost; best_mask = mask; }
+        }
+        GpuTri tmp[4];
+        uint32_t na = 0;
+        for (uint32_t j = 0; j < leaf.cnt; ++j)
+          if (!(best_mask >> j & 1u)) tmp[na++] = out->tris[leaf.first + j];
+        uint32_t w = na;
+        for (uint32_t j = 0; j < leaf.cnt; ++j)
+          if (best_mask >> j & 1u) tmp[w++] = out->tris[leaf.first + j];
+        for (uint32_t j = 0; j < leaf.cnt; ++j) out->tris[leaf.first + j] = tmp[j];
+        Kid a{}, b{};
+        a.inner = b.inner = false;
+        a.first = leaf.first; a.cnt = na;
+        b.first = leaf.first + na; b.cnt = leaf.cnt - na;
+        for (uint32_t j = 0; j < a.cnt; ++j) tri_box(a.first + j, &a.box, j == 0);
+        for (uint32_t j = 0; j < b.cnt; ++j) tri_box(b.first + j, &b.box, j == 0);
+        set[pick] = a;
+        set[n++] = b;
+      }
+      for (int k = 0; k < n; ++k)
+        if (set[k].inner) {
+          id4[set[k].node] = static_cast<uint32_t>(roots.size());
+          roots.push_back(set[k].node);
           depths.push_back(depths[qi] + 1);
         }
-      }
-      kids.push_back(ks);
+      kids.push_back(set);
       nk.push_back(n);
     }
     out->nodes4.resize(roots.size());
@@ -195,10 +260,11 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
       std::memset(&g, 0, sizeof g);
       for (int k = 0; k < 4; ++k) {
         if (k < nk[i]) {
-          rt_aabb const &b = nodes[kids[i][k]].aabb;
+          Kid const &kid = kids[i][k];
+          rt_aabb const &b = kid.box;
           g.lox[k] = b.a.x; g.loy[k] = b.a.y; g.loz[k] = b.a.z;
           g.hix[k] = b.b.x; g.hiy[k] = b.b.y; g.hiz[k] = b.b.z;
-          g.child[k] = nodes[kids[i][k]].type == RT_BVH_INNER ? id4[kids[i][k]] : leaf_ref[kids[i][k]];
+          g.child[k] = kid.inner ? id4[kid.node] : (kLeafBit | (kid.first << 3) | kid.cnt);
           out->nodesq4[4 * i + k] = QuantChild(b, g.child[k], out->grid_lo, out->grid_step);
         } else {  // unused slot: inverted box never passes the slab test
           g.lox[k] = g.loy[k] = g.loz[k] = kFltMax;
@@ -211,7 +277,6 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
     }
     out->depth4 = max4;
     out->stack4 = 3 * max4 + 1;
-    (void)q;
   }
 
   out->root_box = nodes[0].aabb;
@@ -223,6 +288,63 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
   return std::string();
 }
 
+namespace {
+
+struct StackEntry { uint32_t ref; float t; };
+
+// The device's Pop(): entries whose box starts beyond the best hit are dropped unfetched.
+inline uint32_t PopHost(std::vector<StackEntry> &stack, float tbest)
+{
+  while (!stack.empty()) {
+    const StackEntry e = stack.back();
+    stack.pop_back();
+    if (e.t <= tbest) return e.ref;
+  }
+  return 0xFFFFFFFFu;
+}
+
+// The device's Descend2()/Descend4(): continue with the nearest hit child (lowest slot on equal distance), push the
+// others, highest slot deepest.  hit_ref/hit_t/hit_slot list the hit children in slot order.
+inline uint32_t DescendHost(std::vector<StackEntry> &stack, const uint32_t *hit_ref, const float *hit_t, int nh, float tbest)
+{
+  if (nh == 0) return PopHost(stack, tbest);
+  int m = 0;
+  for (int i = 1; i < nh; ++i)
+    if (hit_t[i] < hit_t[m]) m = i;
+  for (int i = nh - 1; i >= 0; --i)
+    if (i != m) stack.push_back({hit_ref[i], hit_t[i]});
+  return hit_ref[m];
+}
+
+// Slab tests of one node of the selected layout; fills the hit children in slot order.
+inline int TestNodeHost(FlatScene const &fs, int width, bool quant, const RayCtx &r, const RayCtxQ &rq, uint32_t cur, float tbest,
+                        uint32_t *hit_ref, float *hit_t)
+{
+  int nh = 0;
+  if (quant) {
+    const int w = width == 4 ? 4 : 2;
+    GpuChildQ const *c = (w == 4 ? fs.nodesq4.data() : fs.nodesq2.data()) + static_cast<size_t>(cur) * w;
+    for (int i = 0; i < w; ++i) {
+      float te;
+      if (SlabTestQ(rq, c[i].x, c[i].y, c[i].z, tbest, te)) { hit_ref[nh] = c[i].ref; hit_t[nh++] = te; }
+    }
+  } else if (width == 4) {
+    GpuNode4 const &n = fs.nodes4[cur];
+    for (int c = 0; c < 4; ++c) {
+      float te;
+      if (SlabTest(r, n.lox[c], n.loy[c], n.loz[c], n.hix[c], n.hiy[c], n.hiz[c], tbest, te)) { hit_ref[nh] = n.child[c]; hit_t[nh++] = te; }
+    }
+  } else {
+    GpuNode2 const &n = fs.nodes2[cur];
+    float te;
+    if (SlabTest(r, n.lo0[0], n.lo0[1], n.lo0[2], n.hi0[0], n.hi0[1], n.hi0[2], tbest, te)) { hit_ref[nh] = n.child[0]; hit_t[nh++] = te; }
+    if (SlabTest(r, n.lo1[0], n.lo1[1], n.lo1[2], n.hi1[0], n.hi1[1], n.hi1[2], tbest, te)) { hit_ref[nh] = n.child[1]; hit_t[nh++] = te; }
+  }
+  return nh;
+}
+
+}  // namespace
+
 // Host mirror of the device traversal (same order, same arithmetic) that only counts.
 FetchCounts CountFetches(FlatScene const &fs, int width, bool quant, rt_ray_isect const *rays, size_t nrays,
                          size_t stride, uint32_t *per_ray)
@@ -231,7 +353,7 @@ FetchCounts CountFetches(FlatScene const &fs, int width, bool quant, rt_ray_isec
   SetQuantGrid(grid, fs.grid_lo, fs.grid_step);
   FetchCounts fc;
   if (stride == 0) stride = 1;
-  std::vector<uint32_t> stack(static_cast<size_t>(std::max(fs.stack2, fs.stack4)) + 8);
+  std::vector<StackEntry> stack;
   for (size_t k = 0; k < nrays; k += stride) {
     RayCtx r;
     SetupRay(r, rays[k].origin.x, rays[k].origin.y, rays[k].origin.z, rays[k].direction.x, rays[k].direction.y,
@@ -240,55 +362,17 @@ FetchCounts CountFetches(FlatScene const &fs, int width, bool quant, rt_ray_isec
     SetupRayQ(rq, r, grid, fs.scale);
     float tbest = kFltMax;
     uint32_t best = 0xFFFFFFFFu;
-    size_t sp = 0;
+    stack.clear();
     uint32_t cur = 0;
     const uint64_t nodes_before = fc.nodes, tris_before = fc.tris;
-    for (;;) {
+    while (cur != 0xFFFFFFFFu) {
       if (!(cur & kLeafBit)) {
         fc.nodes++;
         uint32_t hit_ref[4];
         float hit_t[4];
-        int nh = 0;
-        if (quant) {
-          const int w = width == 4 ? 4 : 2;
-          GpuChildQ const *c = (w == 4 ? fs.nodesq4.data() : fs.nodesq2.data()) + static_cast<size_t>(cur) * w;
-          for (int i = 0; i < w; ++i) {
-            float te;
-            if (SlabTestQ(rq, c[i].x, c[i].y, c[i].z, tbest, te)) {
-              hit_ref[nh] = c[i].ref;
-              hit_t[nh++] = te;
-            }
-          }
-        } else if (width == 4) {
-          GpuNode4 const &n = fs.nodes4[cur];
-          for (int c = 0; c < 4; ++c) {
-            float te;
-            if (SlabTest(r, n.lox[c], n.loy[c], n.loz[c], n.hix[c], n.hiy[c], n.hiz[c], tbest, te)) {
-              hit_ref[nh] = n.child[c];
-              hit_t[nh++] = te;
-            }
-          }
-        } else {
-          GpuNode2 const &n = fs.nodes2[cur];
-          float te;
-          if (SlabTest(r, n.lo0[0], n.lo0[1], n.lo0[2], n.hi0[0], n.hi0[1], n.hi0[2], tbest, te)) {
-            hit_ref[nh] = n.child[0];
-            hit_t[nh++] = te;
-          }
-          if (SlabTest(r, n.lo1[0], n.lo1[1], n.lo1[2], n.hi1[0], n.hi1[1], n.hi1[2], tbest, te)) {
-            hit_ref[nh] = n.child[1];
-            hit_t[nh++] = te;
-          }
-        }
-        // nearest first; stable for equal entry distances (lower slot first)
-        for (int i = 1; i < nh; ++i)
-          for (int j = i; j > 0 && hit_t[j] < hit_t[j - 1]; --j) {
-            std::swap(hit_t[j], hit_t[j - 1]);
-            std::swap(hit_ref[j], hit_ref[j - 1]);
-          }
-        for (int i = nh - 1; i >= 1; --i) stack[sp++] = hit_ref[i];
-        fc.max_stack = std::max<uint64_t>(fc.max_stack, sp);
-        if (nh > 0) { cur = hit_ref[0]; continue; }
+        const int nh = TestNodeHost(fs, width, quant, r, rq, cur, tbest, hit_ref, hit_t);
+        cur = DescendHost(stack, hit_ref, hit_t, nh, tbest);
+        fc.max_stack = std::max<uint64_t>(fc.max_stack, stack.size());
       } else {
         const uint32_t first = (cur & ~kLeafBit) >> 3, cnt = cur & 7u;
         if (cnt) fc.leaves++;
@@ -302,9 +386,8 @@ FetchCounts CountFetches(FlatScene const &fs, int width, bool quant, rt_ray_isec
             best = g.id;
           }
         }
+        cur = PopHost(stack, tbest);
       }
-      if (sp == 0) break;
-      cur = stack[--sp];
     }
     if (best != 0xFFFFFFFFu) fc.rays_hit++;
     if (per_ray) {
@@ -334,7 +417,7 @@ struct LaneSim {
   float tbest = kFltMax;
   uint32_t best = 0xFFFFFFFFu;
   uint32_t cur = 0xFFFFFFFFu;  // kDone
-  std::vector<uint32_t> stack;
+  std::vector<StackEntry> stack;
   bool busy = false;
 };
 
@@ -400,7 +483,7 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
           for (auto &d : lanes) if (d.cur != kDoneRef && d.stack.size() >= 2 && (!donor || d.stack.size() > donor->stack.size())) donor = &d;
           if (!donor) break;
           h.r = donor->r; h.rq = donor->rq; h.tbest = donor->tbest; h.best = donor->best;
-          h.cur = donor->stack.front();
+          h.cur = donor->stack.front().ref;
           donor->stack.erase(donor->stack.begin());
           h.stack.clear();
           events++;
@@ -436,26 +519,9 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
         }
         for (auto &l : lanes) {
           if (l.cur & kLeafBit) continue;
-          uint32_t hit_ref[4]; float hit_t[4]; int nh = 0;
-          const int wd = width == 4 ? 4 : 2;
-          if (quant) {
-            GpuChildQ const *c = (wd == 4 ? fs.nodesq4.data() : fs.nodesq2.data()) + static_cast<size_t>(l.cur) * wd;
-            for (int i = 0; i < wd; ++i) { float te; if (SlabTestQ(l.rq, c[i].x, c[i].y, c[i].z, l.tbest, te)) { hit_ref[nh] = c[i].ref; hit_t[nh++] = te; } }
-          } else if (wd == 4) {
-            GpuNode4 const &n = fs.nodes4[l.cur];
-            for (int i = 0; i < 4; ++i) { float te; if (SlabTest(l.r, n.lox[i], n.loy[i], n.loz[i], n.hix[i], n.hiy[i], n.hiz[i], l.tbest, te)) { hit_ref[nh] = n.child[i]; hit_t[nh++] = te; } }
-          } else {
-            GpuNode2 const &n = fs.nodes2[l.cur];
-            float te;
-            if (SlabTest(l.r, n.lo0[0], n.lo0[1], n.lo0[2], n.hi0[0], n.hi0[1], n.hi0[2], l.tbest, te)) { hit_ref[nh] = n.child[0]; hit_t[nh++] = te; }
-            if (SlabTest(l.r, n.lo1[0], n.lo1[1], n.lo1[2], n.hi1[0], n.hi1[1], n.hi1[2], l.tbest, te)) { hit_ref[nh] = n.child[1]; hit_t[nh++] = te; }
-          }
-          for (int i = 1; i < nh; ++i)
-            for (int j = i; j > 0 && hit_t[j] < hit_t[j - 1]; --j) { std::swap(hit_t[j], hit_t[j - 1]); std::swap(hit_ref[j], hit_ref[j - 1]); }
-          for (int i = nh - 1; i >= 1; --i) l.stack.push_back(hit_ref[i]);
-          if (nh) l.cur = hit_ref[0];
-          else if (l.stack.empty()) l.cur = kDoneRef;
-          else { l.cur = l.stack.back(); l.stack.pop_back(); }
+          uint32_t hit_ref[4]; float hit_t[4];
+          const int nh = TestNodeHost(fs, width, quant, l.r, l.rq, l.cur, l.tbest, hit_ref, hit_t);
+          l.cur = DescendHost(l.stack, hit_ref, hit_t, nh, l.tbest);
         }
       }
       // leaf phase: the wave loops max(count) times
@@ -473,8 +539,7 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
           if (TriTest(g.ax, g.ay, g.az, g.e1x, g.e1y, g.e1z, g.e2x, g.e2y, g.e2z, l.r, t, u, v) &&
               (t < l.tbest || (t == l.tbest && g.id < l.best))) { l.tbest = t; l.best = g.id; }
         }
-        if (l.stack.empty()) l.cur = kDoneRef;
-        else { l.cur = l.stack.back(); l.stack.pop_back(); }
+        l.cur = PopHost(l.stack, l.tbest);
       }
     }
   }

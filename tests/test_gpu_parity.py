@@ -282,6 +282,29 @@ def test_fetch_counters_agree_between_host_and_device(rt, gpu):
         scene.close()
 
 
+def test_stack_spill_to_private_memory_is_exact(rt, oracle, gpu):
+    """The traversal stack keeps `lds_stack` entries per lane in LDS and spills deeper ones to private memory.
+    Incoherent rays through bunny_big go deeper than 8 entries; with the LDS part at its minimum the spill path
+    carries real traffic and every record must still equal the all-LDS launch and the oracle."""
+    import torch
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny_big.obj"), "tolerant")
+    bvh = rt.BVH(mesh, "fixed")
+    rays = rt.ao_rays(mesh, bvh.root_box, 99, 0, 1 << 17)
+    d_rays = torch.from_numpy(rays).cuda()
+    for width in (4, 2):
+        scene = rt.Scene(mesh, bvh, device=gpu, width=width)
+        scene.set_param("lds_stack", 32)
+        deep = scene.count_fetches_device(d_rays.data_ptr(), len(rays))["max_stack"]
+        want = scene.intersect(rays)
+        scene.set_param("lds_stack", 8)
+        got = scene.intersect(rays)
+        scene.close()
+        if width == 4:
+            assert deep > 8, f"test rays too shallow to spill (deepest stack {deep})"
+            compare(rt, oracle, mesh, rays, got, np.arange(0, len(rays), 257))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), width
+
+
 def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
     """Dispatch order, cost feedback between launches, step scheduling threshold and workgroup size only
     decide WHEN a ray is traced.  Every setting, and every repeat of a launch (the feedback order changes
@@ -298,6 +321,10 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
         dict(image_width=W, centre_first=1),
         dict(image_width=W, feedback=1),
         dict(image_width=0, feedback=1),
+        dict(image_width=W, persistent=1),
+        dict(image_width=W, persistent=1, feedback=1),
+        dict(image_width=0, persistent=1, persistent_waves=3),
+        dict(image_width=W, lds_stack=8),
         dict(image_width=W, feedback=1, block_threads=256),
         dict(image_width=W, feedback=1, block_threads=128, feedback_radius=0),
         dict(image_width=W, feedback=1, feedback_radius=3, feedback_share=128),
@@ -307,8 +334,8 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
         dict(image_width=W, leaf_pct=37, block_threads=128, width=4),
         dict(image_width=W, quantized=0, feedback=1, width=4),
     ]
-    defaults = dict(width=2, quantized=1, block_threads=64, image_width=0, leaf_pct=50,
-                    centre_first=1, feedback=0, feedback_radius=1, feedback_share=96)
+    defaults = dict(width=2, quantized=1, block_threads=64, image_width=0, leaf_pct=50, persistent=0,
+                    persistent_waves=24, lds_stack=12, centre_first=1, feedback=0, feedback_radius=1, feedback_share=96)
     for cfg in settings:
         for k, v in {**defaults, **cfg}.items():
             scene.set_param(k, v)

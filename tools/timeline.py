@@ -8,7 +8,7 @@ import raytrace_amd as rt
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else ""
 mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, "dragon.obj"), "tolerant")
-bvh = rt.BVH(mesh, os.environ.get("RT_BVH", "sah"))
+bvh = rt.BVH(mesh, os.environ.get("RT_BVH", "fixed"))
 scene = rt.Scene(mesh, bvh, device=0)
 W, H = 1920, 1080
 for kv in cfg.split(","):
