@@ -1,49 +1,56 @@
 #!/usr/bin/env python3
 """bench.py -- closest-hit Mrays/s on MI355X.
 
-A "step" is one pass of the hot path (ray_scene_intersection's device form,
-rt_intersect_async) over one batch of rays that is already resident in HBM.
+A "step" is one pass of the hot path (ray_scene_intersection's device form, rt_intersect_async) over one
+batch of rays that is already resident in HBM.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] ...
 
 Workloads:
-  dragon1080   dragon.obj 1920x1080 primary rays           (default; the headline metric)
+  dragon1080   dragon.obj 1920x1080 primary rays           (default with one GPU; the headline metric)
+  tiles4k      dragon.obj 3840x2160, image tiles sharded over the ranks by measured traversal cost; every step
+               ends with the compact framebuffer gathered to rank 0 over RCCL and scattered into the row-major
+               image on the device (default with N > 1: strong scaling, the gather and scatter are inside the
+               timed step and also reported on their own)
   bunny1080    bunny.obj 1920x1080 primary rays
-  dragon4k     dragon.obj 3840x2160 primary rays
-  ao           bunny_big.obj incoherent AO-style rays (--rays, default 16 Mi per GPU)
+  dragon4k     dragon.obj 3840x2160 primary rays on one GPU
+  ao           bunny_big.obj incoherent AO-style rays (--rays per GPU, default 64 Mi)
   mirror5      cube_mirror_test.obj 1920x1080: one step = the primary pass + four reflection passes of the
                full `trace` kernel (rt_trace_pass, records ping-ponged on the device); rays counted = 5 x W x H
-  tiles4k      dragon.obj 3840x2160 split by interleaved 64x64 tiles over the ranks, with the
-               compact framebuffer gathered to rank 0 over RCCL (strong scaling; the gather is
-               timed inside the step and also reported on its own)
+  frames       with N > 1: every rank traces its own dragon1080 frame (weak scaling, no exchange)
 
-With N > 1 (one process per GPU under torch.distributed.run) every rank traces its own
-frame of the workload (rank r's camera is shifted sideways by r steps), so per-GPU work is
-fixed and the job's rays/s is the sum: weak scaling, no data-path collective.  `tiles4k` is
-the sharded-image form with its one exchange step.
+The scene is built the way the reference builds it: tolerant OBJ load, core/CentroidBVH build with the
+centroid-index repair (--bvh fixed).  --bvh sah swaps in the library's surface-area builder.
 
-Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch / mean
-launch duration (HIP events on the launch stream).  `cpu_baseline` times the CPU oracle
-(brute force over all triangles, the reference's cpu_raycast loop) on a bounded sample.
+Rank 0 prints ONE JSON line.  `roofline` carries one fraction per resource (hbm: compulsory ray/hit stream
+bytes against the 8 TB/s HBM3E peak; l2: L1-miss requests against the request rate a gather microbenchmark
+reaches on this chip; valu: cycles in which the SIMDs issue vector instructions against all SIMD cycles);
+`frac` is the largest and `bound` names it.  Counter-derived inputs come from committed rocprofv3 passes
+(profiles/rNN/pmc_table.json) and are divided by the launch duration measured live with HIP events.
+`cpu_baseline` times the CPU oracle (brute force over all triangles, the reference's cpu_raycast loop) on a
+bounded sample.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
-import sys
 import time
 
 import numpy as np
 import torch  # before raytrace_amd: both must bind the same HIP runtime
 
 import raytrace_amd as rt
-from raytrace_amd.tiles import tile_indices
+from raytrace_amd import tiles as tl
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
+SIMDS = 256 * 4             # vector units on the chip
+CLOCK_HZ = 2.4e9            # peak engine clock: the denominator of the VALU fraction
+ROOT = os.path.dirname(os.path.abspath(__file__))
 
 WORKLOADS = {
     "dragon1080": ("dragon.obj", 1920, 1080),
+    "frames": ("dragon.obj", 1920, 1080),
     "bunny1080": ("bunny.obj", 1920, 1080),
     "dragon4k": ("dragon.obj", 3840, 2160),
     "tiles4k": ("dragon.obj", 3840, 2160),
@@ -57,22 +64,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="dragon1080", choices=sorted(WORKLOADS))
-    ap.add_argument("--width", type=int, default=int(os.environ.get("RT_WIDTH", "0")), help="2 or 4 (0 = library default)")
-    ap.add_argument("--rays", type=int, default=16 * 1024 * 1024, help="ray count for --workload ao")
-    ap.add_argument("--bvh", default="sah", choices=["fixed", "reference", "sah"],
+    ap.add_argument("--workload", default="", choices=[""] + sorted(WORKLOADS),
+                    help="default: dragon1080 on one GPU, tiles4k on several")
+    ap.add_argument("--width", type=int, default=4, help="children per node record the traversal walks: 2 or 4")
+    ap.add_argument("--rays", type=int, default=64 * 1024 * 1024, help="ray count per GPU for --workload ao")
+    ap.add_argument("--bvh", default="fixed", choices=["fixed", "reference", "sah"],
                     help="tree handed to rt_scene_create: the reference's centroid build as written (reference), with its "
-                         "centroid indexing repaired (fixed), or the surface-area build in the same node format (sah)")
+                         "centroid indexing repaired (fixed, the default), or the surface-area build in the same node format (sah)")
     ap.add_argument("--out", default="full", choices=["full", "compact"], help="64-byte hit records or 16-byte {id,t,u,v}")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-compare", action="store_true", help="skip the extra timing on the centroid tree")
+    ap.add_argument("--no-compare", action="store_true", help="skip the extra timing on the surface-area tree")
     ap.add_argument("--cpu-stride", type=int, default=4, help="sub-grid stride (both axes) of the CPU baseline sample")
-    ap.add_argument("--tile", type=int, default=64)
-    ap.add_argument("--extra-stack", type=int, default=0, help="diagnostic: extra LDS per lane to lower occupancy")
-    ap.add_argument("--quant", type=int, default=-1, help="1: 16-bit quantized boxes, 0: float boxes (-1 = library default)")
-    ap.add_argument("--block", type=int, default=0, help="workgroup threads: 64, 128 or 256 (0 = library default)")
+    ap.add_argument("--tile", type=int, default=64, help="tiles4k: side of the squares dealt to the ranks (multiple of 8)")
+    ap.add_argument("--assign", default="cost", choices=["cost", "roundrobin"], help="tiles4k: how squares are dealt to ranks")
     ap.add_argument("--image-hint", type=int, default=1, help="declare the ray array as a W-wide image (8x8 tiles per wave)")
-    ap.add_argument("--waves-per-cu", type=int, default=-1, help="resident-wave cap per CU (-1 = library default)")
     ap.add_argument("--raygen", default="table", choices=["table", "device"],
                     help="table: rays are a RayIntersection array resident in HBM (the reference's interface); device: "
                          "the same primary rays are generated inside the kernel (rt_trace_primary), no ray array is read")
@@ -82,29 +87,41 @@ def parse():
     ap.add_argument("--frames", type=int, default=4,
                     help="image workloads: distinct camera positions (ray tables, all resident in HBM) the steps cycle "
                          "through, so that no step repeats the previous step's rays")
-    ap.add_argument("--feedback-radius", type=int, default=-1, help="-1 = library default")
-    ap.add_argument("--feedback-share", type=int, default=-1, help="-1 = library default")
-    ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
-                    help="extra rt_scene_set_param settings (repeatable), applied last")
     ap.add_argument("--feedback", type=int, default=1,
                     help="1: each launch starts its work units costliest-first, by the costs measured two launches earlier")
+    ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra rt_scene_set_param settings (repeatable), applied last")
     return ap.parse_args()
 
 
-def measured_traffic(workload, out_bytes, world):
-    """(GB per launch, file) from the newest profiles/r*/hbm_traffic.json that has this workload, else (None, None)."""
-    if world != 1:
-        return None, None
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    key = f"{workload}/out{out_bytes}"
+def newest_profile_table(name):
+    """Contents and path of the newest profiles/r*/<name>, or ({}, None)."""
+    root = os.path.join(ROOT, "profiles")
     for d in sorted((x for x in os.listdir(root) if x.startswith("r")), reverse=True) if os.path.isdir(root) else []:
-        path = os.path.join(root, d, "hbm_traffic.json")
+        path = os.path.join(root, d, name)
         if os.path.exists(path):
             with open(path) as f:
-                table = json.load(f)
-            if key in table:
-                return table[key]["gb_per_launch"], f"profiles/{d}/hbm_traffic.json"
-    return None, None
+                return json.load(f), f"profiles/{d}/{name}"
+    return {}, None
+
+
+def timed(dist, steps, fn):
+    """Runs fn() `steps` times between barriers; returns (wall seconds, device ms per step by events on the current stream)."""
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    return time.perf_counter() - t0, ev0.elapsed_time(ev1) / max(1, steps)
 
 
 def main():
@@ -127,62 +144,75 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo")
-    red_dev = "cuda" if a.backend == "nccl" else "cpu"   # where the two scalar reductions below live
+    red_dev = "cuda" if a.backend == "nccl" else "cpu"   # where the scalar reductions below live
+    workload = a.workload or ("dragon1080" if world == 1 else "tiles4k")
+    sharded = workload == "tiles4k"
 
-    model, W, H = WORKLOADS[a.workload]
-    mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "reference" if a.workload == "mirror5" else "tolerant")
+    model, W, H = WORKLOADS[workload]
+    mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "reference" if workload == "mirror5" else "tolerant")
     bvh = rt.BVH(mesh, a.bvh)
-    scene = rt.Scene(mesh, bvh, device=local, width=4 if a.width == 4 else 2)
-    if a.width in (2, 4):
-        scene.set_param("width", a.width)
-    if a.extra_stack > 0:
-        scene.set_param("extra_stack", a.extra_stack)
-    if a.quant >= 0:
-        scene.set_param("quantized", a.quant)
-    if a.block > 0:
-        scene.set_param("block_threads", a.block)
-    if W and a.workload != "tiles4k" and a.image_hint:
-        scene.set_param("image_width", W)
-    elif a.workload == "tiles4k" and a.image_hint and W % a.tile == 0:
-        # a rank's rays are its tiles one after another, each row-major and a.tile pixels wide: to the library that
-        # is an image a.tile wide and (tiles x rows) tall, so waves still take 8x8 pixel blocks
-        scene.set_param("image_width", a.tile)
-    scene.set_param("feedback", a.feedback)
-    if a.feedback_radius >= 0:
-        scene.set_param("feedback_radius", a.feedback_radius)
-    if a.feedback_share >= 0:
-        scene.set_param("feedback_share", a.feedback_share)
-    if a.waves_per_cu >= 0:
-        scene.set_param("waves_per_cu", a.waves_per_cu)
-    for kv in a.param:
-        k, v = kv.split("=")
-        scene.set_param(k, int(v))
+    width = 4 if a.width == 4 else 2
+
+    def make_scene(tree):
+        sc = rt.Scene(mesh, tree, device=local, width=width)
+        sc.set_param("width", width)
+        sc.set_param("feedback", a.feedback)
+        for kv in a.param:
+            k, v = kv.split("=")
+            sc.set_param(k, int(v))
+        return sc
+
+    scene = make_scene(bvh)
     info = scene.info()
     box = bvh.root_box
+    stream = torch.cuda.current_stream().cuda_stream
+    extra = {}
 
     # ---- synthetic input, generated on the host once, resident in HBM before timing ----
-    if a.workload == "ao":
+    all_lists = None
+    if workload == "ao":
         n_local = a.rays
-        rays_h = rt.ao_rays(mesh, box, 1234, rank * n_local, n_local)
-        own = None
+        # generated and uploaded in slices: the host table of 64 Mi records would be 4.3 GB
+        rays_d = torch.empty((n_local, 16), dtype=torch.float32, device="cuda")
+        piece = 4 * 1024 * 1024
+        rays_h = None
+        for off in range(0, n_local, piece):
+            part = rt.ao_rays(mesh, box, 1234, rank * n_local + off, min(piece, n_local - off))
+            if off == 0:
+                rays_h = part            # the first slice stays on the host for the CPU sample and the fetch counter
+            rays_d[off:off + len(part)].copy_(torch.from_numpy(part))
+        frames, origins, tables = 1, [], [rays_d]
     else:
         origin = rt.frame_camera(box, W, H)
-        if a.workload == "tiles4k":
+        if sharded:
+            assert a.tile % 8 == 0
+            tx, ty = tl.tile_grid(W, H, a.tile)
+            # every rank measures the same per-square costs with one untimed pass of its own (deterministic wave
+            # iteration counts), so all ranks derive the same assignment without exchanging anything
+            costs = tl.tile_costs_from_units(scene.unit_costs_primary(W, H, origin), W, H, a.tile)
+            all_lists = tl.assign_tiles(tx * ty, world, costs if a.assign == "cost" else None)
+            idx, _ = tl.rays_of_tiles(W, H, a.tile, all_lists[rank])
             full = rt.primary_rays(W, H, origin)
-            own = tile_indices(W, H, a.tile, rank, world)
-            rays_h = full[own]
+            rays_h = full[idx]
             del full
+            extra["tile_assignment"] = {"squares": int(tx * ty), "side": a.tile, "by": a.assign,
+                                        "modelled_max_over_mean_cost": round(tl.balance(all_lists, costs), 4),
+                                        "round_robin_would_be": round(tl.balance(tl.assign_tiles(tx * ty, world, None), costs), 4)}
+            if a.image_hint and W % a.tile == 0:
+                # a rank's rays are its squares one after another, each row-major and a.tile pixels wide: to the library
+                # that is an image a.tile wide and (squares x rows) tall, so waves still take 8x8 pixel blocks
+                scene.set_param("image_width", a.tile)
         else:
             origin[0] += rank * 0.01 * float(box[1, 0] - box[0, 0])  # each rank renders its own frame
             rays_h = rt.primary_rays(W, H, origin)
-            own = None
+            if a.image_hint:
+                scene.set_param("image_width", W)
         n_local = len(rays_h)
-    rays_d = torch.from_numpy(rays_h).cuda()
-    # A render loop never traces the same rays twice: frame k of the timed loop looks from origin_k, a camera
-    # that drifts sideways by 0.2 % of the scene width per frame and returns after `frames` frames.
-    frames = max(1, a.frames) if a.workload in ("dragon1080", "bunny1080", "dragon4k") else 1
-    origins, tables = [], [rays_d]
-    if a.workload != "ao":
+        rays_d = torch.from_numpy(rays_h).cuda()
+        # A render loop never traces the same rays twice: frame k of the timed loop looks from origin_k, a camera
+        # that drifts sideways by 0.2 % of the scene width per frame and returns after `frames` frames.
+        frames = max(1, a.frames) if workload in ("dragon1080", "frames", "bunny1080", "dragon4k") else 1
+        origins, tables = [], [rays_d]
         for k in range(frames):
             o = origin.copy()
             o[0] += k * 0.002 * float(box[1, 0] - box[0, 0])
@@ -190,44 +220,62 @@ def main():
             if k > 0 and a.raygen == "table":
                 tables.append(torch.from_numpy(rt.primary_rays(W, H, o)).cuda())
     step_no = [0]
-    full_out = a.out == "full" or a.workload == "mirror5"
+    full_out = (a.out == "full" or workload == "mirror5") and not sharded
+    out_b = 64 if full_out else 16
     hits_d = torch.empty((n_local, 16 if full_out else 4), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
 
-    gather_bufs = None
-    if a.workload == "tiles4k" and world > 1:
-        counts = [len(tile_indices(W, H, a.tile, r, world)) for r in range(world)]
-        if rank == 0:
-            gather_bufs = [torch.empty((c, 4), dtype=torch.float32, device="cuda") for c in counts]
-        hits16_d = torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
-
-    passes = 5 if a.workload == "mirror5" else 1
-    if a.workload == "mirror5":
+    passes = 5 if workload == "mirror5" else 1
+    if workload == "mirror5":
         pong = torch.empty((n_local, 16), dtype=torch.float32, device="cuda")
         rgba_d = torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
         cam = np.eye(4, dtype=np.float32)
+
+    # ---- sharded image: gather buffer, square lists and the exchange --------------------------------------
+    if sharded:
+        counts = [len(tl.rays_of_tiles(W, H, a.tile, l)[0]) for l in all_lists]
+        bases = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        if rank == 0:
+            gather_d = torch.empty((W * H, 4), dtype=torch.float32, device="cuda")     # squares of rank 0, 1, ... back to back
+            fb_d = torch.empty((W * H, 4), dtype=torch.float32, device="cuda")         # the row-major framebuffer
+            ids_h = np.concatenate(all_lists).astype(np.int32)
+            first_h = np.concatenate([tl.rays_of_tiles(W, H, a.tile, l)[1].astype(np.int64) + bases[r]
+                                      for r, l in enumerate(all_lists)]).astype(np.int32)
+            ids_d, first_d = torch.from_numpy(ids_h).cuda(), torch.from_numpy(first_h).cuda()
+            hits_d = gather_d[:counts[0]]          # rank 0 traces straight into its slice of the gather buffer
+            slices = [gather_d[bases[r]:bases[r + 1]] for r in range(world)]
+
+        def exchange():
+            """One exchange step: every other rank's compact records to rank 0 (point-to-point, grouped: rank 0
+            receives on its seven xGMI links at once, no ring), then the device scatter into the framebuffer."""
+            if world > 1:
+                if rank == 0:
+                    ops = [dist.P2POp(dist.irecv, slices[r], r) for r in range(1, world)]
+                else:
+                    ops = [dist.P2POp(dist.isend, hits_d, 0)]
+                if a.backend == "nccl":
+                    for q in dist.batch_isend_irecv(ops):
+                        q.wait()
+                else:
+                    for q in [op.op(op.tensor, op.peer) for op in ops]:
+                        q.wait()
+            if rank == 0:
+                rt.scatter_tiles(local, gather_d.data_ptr(), W * H, ids_d.data_ptr(), first_d.data_ptr(), len(ids_h), a.tile, W, H, 16,
+                                 fb_d.data_ptr(), stream)
 
     def step():
         k = step_no[0] % frames
         step_no[0] += 1
         rays_k = tables[k] if k < len(tables) else rays_d
-        if a.workload == "mirror5":
+        if workload == "mirror5":
             # pass 0 reads the primary table; passes 1..4 reflect the previous pass's records (ping-pong)
             scene.trace_pass(rays_d.data_ptr(), hits_d.data_ptr(), rgba_d.data_ptr(), n_local, cam, 0, stream)
             src, dst = hits_d, pong
             for _ in range(4):
                 scene.trace_pass(src.data_ptr(), dst.data_ptr(), rgba_d.data_ptr(), n_local, cam, 1, stream)
                 src, dst = dst, src
-        elif a.workload == "tiles4k" and world > 1:
-            scene.intersect_async(rays_d.data_ptr(), n_local, None, hits16_d.data_ptr(), stream)
-            # one exchange: compact hit tiles to rank 0 (point-to-point sends, not a ring)
-            if rank == 0:
-                gather_bufs[0].copy_(hits16_d)
-                reqs = [dist.irecv(gather_bufs[r], src=r) for r in range(1, world)]
-                for q in reqs:
-                    q.wait()
-            else:
-                dist.isend(hits16_d, dst=0).wait()
+        elif sharded:
+            scene.intersect_async(rays_d.data_ptr(), n_local, None, hits_d.data_ptr(), stream)
+            exchange()
         elif a.raygen == "device" and W:
             scene.trace_primary(W, H, origins[k], hits_d.data_ptr() if full_out else None,
                                 None if full_out else hits_d.data_ptr(), stream)
@@ -238,22 +286,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-        torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(a.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-        torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1) / max(1, a.steps)  # mean launch duration on the launch stream
+    wall, dev_ms = timed(dist, a.steps, step)
     dev_ms /= passes
     if dist:
         tt = torch.tensor([wall], dtype=torch.float64, device=red_dev)
@@ -268,122 +301,181 @@ def main():
     ms_per_step = wall * 1e3 / max(1, a.steps)
     mrays = n_total / (ms_per_step * 1e-3) / 1e6
 
+    if sharded:
+        # the parts of the step on their own: trace only (slowest rank), exchange only
+        sub = max(5, a.steps // 4)
+        w_tr, _ = timed(dist, sub, lambda: scene.intersect_async(rays_d.data_ptr(), n_local, None, hits_d.data_ptr(), stream))
+        w_ex, _ = timed(dist, sub, exchange)
+        parts = torch.tensor([w_tr / sub * 1e3, w_ex / sub * 1e3], dtype=torch.float64, device=red_dev)
+        if dist:
+            dist.all_reduce(parts, op=dist.ReduceOp.MAX)
+        extra["trace_only_ms"] = round(float(parts[0]), 4)
+        extra["gather_and_scatter_ms"] = round(float(parts[1]), 4)
+        extra["gather_bytes_into_rank0"] = int((W * H - counts[0]) * 16)
+        if world > 1:
+            # the whole frame on ONE GPU of this job (rank 0 alone, the others wait): the strong-scaling reference point
+            if rank == 0:
+                full_d = torch.from_numpy(rt.primary_rays(W, H, origin)).cuda()
+                one_out = torch.empty((W * H, 4), dtype=torch.float32, device="cuda")
+                scene.set_param("image_width", W)
+                for _ in range(5):
+                    scene.intersect_async(full_d.data_ptr(), W * H, None, one_out.data_ptr(), stream)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(sub):
+                    scene.intersect_async(full_d.data_ptr(), W * H, None, one_out.data_ptr(), stream)
+                torch.cuda.synchronize()
+                one_ms = (time.perf_counter() - t0) / sub * 1e3
+                extra["one_gpu_same_frame"] = {"ms_per_step": round(one_ms, 4), "value": round(W * H / (one_ms * 1e-3) / 1e6, 1),
+                                               "unit": "Mrays/s", "speedup_of_this_job": round(one_ms / ms_per_step, 3)}
+                # the gathered framebuffer must be the single-GPU framebuffer, byte for byte
+                scene.set_param("image_width", a.tile if (a.image_hint and W % a.tile == 0) else 0)
+                step()
+                torch.cuda.synchronize()
+                extra["framebuffer_equals_one_gpu"] = bool(torch.equal(fb_d.view(torch.int32), one_out.view(torch.int32)))
+                del full_d, one_out
+            else:
+                step()
+            dist.barrier()
+
     if rank == 0:
-        # ---- algorithmic bytes per ray: records the traversal fetches, counted exactly ----
-        width = a.width if a.width in (2, 4) else 2
-        if a.workload == "mirror5":
+        # ---- algorithmic bytes per ray: records the traversal fetches, counted exactly by the instrumented kernel ----
+        if workload == "mirror5":
             scene.set_param("feedback", 0)   # the counting launch below is a primary pass only
-        cnt = scene.count_fetches_device(rays_d.data_ptr(), n_local)
-        for extra in tables[1:]:   # records fetched: the mean over the frames the loop cycles through
-            more = scene.count_fetches_device(extra.data_ptr(), n_local)
-            cnt = {key: cnt[key] + more[key] for key in cnt}
-        stride = max(1, n_local // 8192)
+        n_count = min(n_local, 1 << 24)
+        cnt = scene.count_fetches_device(rays_d.data_ptr(), n_count)
+        for more_rays in tables[1:]:   # records fetched: the mean over the frames the loop cycles through
+            more = scene.count_fetches_device(more_rays.data_ptr(), n_count)
+            cnt = {key: (max(cnt[key], more[key]) if key == "max_stack" else cnt[key] + more[key]) for key in cnt}
+        stride = max(1, len(rays_h) // 8192)
         cnt_cpu = scene.count_fetches(rays_h, stride)
         node_b = info["node4_bytes"] if width == 4 else info["node2_bytes"]
         n_node, n_tri = cnt["nodes"] / cnt["rays"], cnt["tris"] / cnt["rays"]
-        out_b = 64 if (full_out and not (a.workload == "tiles4k" and world > 1)) else 16
-        in_b = 0 if (a.raygen == "device" and W and a.workload not in ("tiles4k", "mirror5")) else 64
-        bytes_per_ray = in_b + out_b + n_node * node_b + n_tri * info["tri_bytes"]
-        if a.workload == "mirror5":
-            # reflection passes trace rays that exist only inside the kernel: their records are not counted, so
-            # the figure below prices every pass at the streams alone (record in, record out, RGBA pixel)
-            bytes_per_ray = 64 + 64 + 16
-        achieved = bytes_per_ray * n_local / (dev_ms * 1e-3) / 1e9
+        in_b = 0 if (a.raygen == "device" and W and workload not in ("tiles4k", "mirror5")) else 64
+        stream_b = in_b + out_b + (16 if workload == "mirror5" else 0)       # compulsory HBM bytes per ray
+        trav_b = 0.0 if workload == "mirror5" else n_node * node_b + n_tri * info["tri_bytes"]
+        secs = dev_ms * 1e-3
+        key = f"{workload}/{a.bvh}/w{width}/out{out_b}/{a.raygen}"
+        pmc_table, pmc_src = newest_profile_table("pmc_table.json")
+        pmc = pmc_table.get(key) if world == 1 else None
+        peaks, _ = newest_profile_table("l2_gather_peak.json")
+        res = {"hbm": {"achieved": round(stream_b * n_local / secs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "what": f"compulsory streams: {in_b} B ray in + {out_b} B hit out" + (" + 16 B pixel" if workload == "mirror5" else "")}}
+        res["hbm"]["frac"] = round(res["hbm"]["achieved"] / HBM_PEAK_GBS, 4)
+        traffic = None
+        if pmc:
+            traffic = round((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 / 1e9, 4)
+            res["hbm"]["traffic_over_compulsory"] = round(traffic * 1e9 / (stream_b * n_local), 3)
+            if peaks.get("l2_requests_per_ns_chip"):
+                req = pmc["TCP_TCC_READ_REQ_sum"] / secs / 1e9
+                res["l2"] = {"achieved": round(req, 2), "peak": peaks["l2_requests_per_ns_chip"], "unit": "read requests/ns",
+                             "frac": round(req / peaks["l2_requests_per_ns_chip"], 4),
+                             "what": "L1-miss read requests (TCP_TCC_READ_REQ) per launch / launch time, against the request "
+                                     "rate of a divergent 16-byte gather over an L2-resident table on this chip",
+                             "l1_hit_share": round(1.0 - pmc["TCP_TCC_READ_REQ_sum"] / pmc["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)}
+            busy = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / secs         # the counter ticks once per 4 cycles of VALU issue
+            res["valu"] = {"achieved": round(busy / 1e9, 1), "peak": round(SIMDS * CLOCK_HZ / 1e9, 1), "unit": "G SIMD-cycles/s",
+                           "frac": round(busy / (SIMDS * CLOCK_HZ), 4),
+                           "what": "cycles the SIMDs spend issuing vector instructions (SQ_ACTIVE_INST_VALU x 4) per launch / "
+                                   "launch time, against 1024 SIMDs x 2.4 GHz",
+                           "instructions_per_wave": round(pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"], 1),
+                           "lane_utilisation": round(pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0), 4)}
+        bound = max(res, key=lambda k: res[k]["frac"])
+        ops = n_node * width * 24 + n_tri * 52     # lane operations the algorithm needs: 24 per box test, 52 per triangle test
         roofline = {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "ClosestHitKernel", "kernel_ms": round(dev_ms, 4), "bytes_per_ray": round(bytes_per_ray, 1),
-            "node_records_per_ray": round(n_node, 3), "tri_records_per_ray": round(n_tri, 3),
-            "node_records_per_ray_cpu_sample": round(cnt_cpu["nodes"] / max(1, cnt_cpu["rays"]), 3),
-            "tri_records_per_ray_cpu_sample": round(cnt_cpu["tris"] / max(1, cnt_cpu["rays"]), 3),
-            "node_bytes": node_b, "tri_bytes": info["tri_bytes"], "ray_in_bytes": in_b, "hit_out_bytes": out_b,
-            "hit_fraction": round(cnt["rays_hit"] / cnt["rays"], 4),
-            # the two parts of the algorithmic figure on their own: the compulsory ray/hit streams (what HBM must
-            # move) and the traversal records (served by L1/L2; the L2 sustains roughly 17-19 TB/s of gathers)
-            "stream_GBs": round((in_b + out_b) * n_local / (dev_ms * 1e-3) / 1e9, 1),
-            "traversal_GBs": round((bytes_per_ray - in_b - out_b) * n_local / (dev_ms * 1e-3) / 1e9, 1),
+            "bound": bound, "achieved": res[bound]["achieved"], "peak": res[bound]["peak"], "unit": res[bound]["unit"],
+            "frac": res[bound]["frac"], "traffic": traffic, "traffic_unit": "GB per launch, HBM side (2 x FETCH_SIZE + WRITE_SIZE)",
+            "resources": res, "counters_from": pmc_src if pmc else None, "counters_key": key,
+            "kernel": "ClosestHitKernel", "kernel_ms": round(dev_ms, 4),
+            # the algorithmic traversal figure, never compared with the HBM peak: most of it is served by L1/L2
+            "algorithmic": {"bytes_per_ray": round(stream_b + trav_b, 1), "stream_bytes_per_ray": stream_b,
+                            "node_records_per_ray": round(n_node, 3), "tri_records_per_ray": round(n_tri, 3),
+                            "node_bytes": node_b, "tri_bytes": info["tri_bytes"],
+                            "node_records_per_ray_cpu_sample": round(cnt_cpu["nodes"] / max(1, cnt_cpu["rays"]), 3),
+                            "tri_records_per_ray_cpu_sample": round(cnt_cpu["tris"] / max(1, cnt_cpu["rays"]), 3),
+                            "traversal_GBs": round(trav_b * n_local / secs / 1e9, 1),
+                            "hit_fraction": round(cnt["rays_hit"] / cnt["rays"], 4), "deepest_stack": cnt["max_stack"],
+                            "valu_lane_ops_per_ray": round(ops, 1),
+                            "valu_lane_ops_frac_of_peak": round(ops * n_local / secs / (SIMDS * 32 * CLOCK_HZ), 4)},
         }
-        # The resource this kernel actually saturates is FP32 vector issue, not memory: algorithmic lane operations
-        # (24 per box test, two boxes per node record; 52 per triangle test incl. the divide) against the rate at
-        # which 256 CUs x 64 lanes retire one non-fused operation per clock at 2.4 GHz.  The issue and lane
-        # utilisation measured by PMC counters are in the committed profile summary.
-        ops_per_ray = n_node * (4 if width == 4 else 2) * 24 + n_tri * 52
-        roofline["valu"] = {"algorithmic_ops_per_ray": round(ops_per_ray, 1),
-                            "achieved_Tops": round(ops_per_ray * n_local / (dev_ms * 1e-3) / 1e12, 2),
-                            "peak_Tops": round(256 * 64 * 2.4e9 / 1e12, 1),
-                            "frac": round(ops_per_ray * n_local / (dev_ms * 1e-3) / (256 * 64 * 2.4e9), 4)}
-        # HBM-side bytes per launch from PMC counters: measured in separate rocprofv3 passes (tools/profile_gpu.sh),
-        # committed next to the kernel-trace summary, looked up here by workload and output record
-        roofline["traffic"], roofline["traffic_source"] = measured_traffic(a.workload, out_b, world)
-        roofline["traffic_unit"] = "GB per launch (2 x FETCH_SIZE + WRITE_SIZE)"
 
-        # the same launch on the reference's own (repaired) centroid tree, for comparison
-        centroid = None
-        if world == 1 and a.bvh == "sah" and not a.no_compare and a.workload in ("dragon1080", "bunny1080", "dragon4k"):
-            bvh_c = rt.BVH(mesh, "fixed")
-            scene_c = rt.Scene(mesh, bvh_c, device=local, width=4 if a.width == 4 else 2)
-            for k, v in (("quantized", a.quant), ("block_threads", a.block)):
-                if v > 0 or (k == "quantized" and v == 0):
-                    scene_c.set_param(k, v)
+        # the same launch on the library's surface-area tree (an extension: same node format, fewer records per ray)
+        other = None
+        if world == 1 and a.bvh == "fixed" and not a.no_compare and workload in ("dragon1080", "bunny1080", "dragon4k"):
+            scene_s = make_scene(rt.BVH(mesh, "sah"))
             if a.image_hint:
-                scene_c.set_param("image_width", W)
-            scene_c.set_param("feedback", a.feedback)
+                scene_s.set_param("image_width", W)
+            out_args = (hits_d.data_ptr(), None) if full_out else (None, hits_d.data_ptr())
+            k_no = [0]
+
+            def step_s():
+                k_no[0] += 1
+                scene_s.intersect_async(tables[k_no[0] % len(tables)].data_ptr(), n_local, out_args[0], out_args[1], stream)
             for _ in range(a.warmup):
-                scene_c.intersect_async(rays_d.data_ptr(), n_local, hits_d.data_ptr() if full_out else None,
-                                        None if full_out else hits_d.data_ptr(), stream)
-            torch.cuda.synchronize()
-            c0 = time.perf_counter()
-            for _ in range(a.steps):
-                scene_c.intersect_async(rays_d.data_ptr(), n_local, hits_d.data_ptr() if full_out else None,
-                                        None if full_out else hits_d.data_ptr(), stream)
-            torch.cuda.synchronize()
-            cms = (time.perf_counter() - c0) * 1e3 / max(1, a.steps)
-            centroid = {"bvh": "fixed", "ms_per_step": round(cms, 4), "value": round(n_local / (cms * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
-            scene_c.close()
+                step_s()
+            w_s, _ = timed(None, a.steps, step_s)
+            sms = w_s * 1e3 / max(1, a.steps)
+            other = {"bvh": "sah", "ms_per_step": round(sms, 4), "value": round(n_local / (sms * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
+            scene_s.close()
 
         step_no[0] = 0
-        step()                      # leaves frame 0's hits in hits_d for the spot check below
+        if not sharded:
+            step()                      # leaves frame 0's hits in hits_d for the spot check below
         torch.cuda.synchronize()
         cpu = None
-        if world == 1 and not a.no_cpu_baseline and a.workload != "mirror5":
+        if world == 1 and not a.no_cpu_baseline and workload != "mirror5":
             import oracle  # the CPU checker, used here only as the timed baseline
-            if a.workload == "ao":
-                sample = rays_h[:: max(1, n_local // 16384)]
-                what = f"{len(sample)} of the {n_local} rays (every {max(1, n_local // 16384)}th)"
+            if workload == "ao":
+                every = max(1, len(rays_h) // 16384)
+                sel = np.arange(0, len(rays_h), every)
+                what = f"{len(sel)} of the {n_local} rays (every {every}th of the first {len(rays_h)}) x {len(mesh.faces)} triangles, brute force"
             else:
                 s = a.cpu_stride
-                grid = (np.arange(0, H, s)[:, None] * W + np.arange(0, W, s)[None, :]).reshape(-1)
-                sample = rays_h[grid]
-                what = f"stride-{s} sub-grid of the {W}x{H} ray set ({len(sample)} rays x {len(mesh.faces)} triangles, brute force)"
+                sel = (np.arange(0, H, s)[:, None] * W + np.arange(0, W, s)[None, :]).reshape(-1)
+                what = f"stride-{s} sub-grid of the {W}x{H} ray set ({len(sel)} rays x {len(mesh.faces)} triangles, brute force)"
+            sample = rays_h[sel] if not sharded else rt.primary_rays(W, H, origin)[sel]
             threads = oracle.default_threads()
             c0 = time.perf_counter()
             oid, ot, _, _ = oracle.closest_hit(mesh.verts, mesh.faces, sample, threads=threads)
             cdt = time.perf_counter() - c0
             # parity spot-check of the same sample against the GPU result of the last step
-            hits_h = hits_d.cpu().numpy()
-            gid = hits_h[:, 14 if full_out else 0].view(np.uint32)
-            sel = grid if a.workload != "ao" else np.arange(0, n_local, max(1, n_local // 16384))
-            mism = int((gid[sel] != oid).sum()) if a.workload != "tiles4k" else None
+            src = fb_d if sharded else hits_d
+            got = src[torch.from_numpy(sel).cuda()].cpu().numpy()
+            gid = got[:, 14 if full_out else 0].view(np.uint32)
+            gt = got[:, 15 if full_out else 1]
+            hit = oid != rt.MISS_ID
             cpu = {"value": round(len(sample) / cdt / 1e6, 6), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                   "sample": what, "seconds": round(cdt, 2), "id_mismatches_vs_gpu": mism}
+                   "sample": what, "seconds": round(cdt, 2), "id_mismatches_vs_gpu": int((gid != oid).sum()),
+                   "t_bit_mismatches_vs_gpu": int((gt[hit].view(np.uint32) != ot[hit].view(np.uint32)).sum())}
 
+        if workload == "mirror5":
+            what = f"{model} {W}x{H} primary pass + 4 reflection passes (full trace kernel)"
+        elif sharded:
+            what = f"{model} {W}x{H} primary rays, image tiles sharded over {world} GPU(s), framebuffer gathered to rank 0"
+        elif W:
+            what = f"{model} {W}x{H} primary rays"
+        else:
+            what = f"{model} {n_local} AO rays per GPU"
         line = {
             "metric": "closest-hit Mrays/s", "value": round(mrays, 1), "unit": "Mrays/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong" if a.workload == "tiles4k" else "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{model} {W}x{H} primary pass + 4 reflection passes (full trace kernel)" if a.workload == "mirror5"
-                       else f"{model} {W}x{H} primary rays" if W else f"{model} {n_local} AO rays per GPU",
-                       "name": a.workload, "rays_per_gpu": n_local, "rays_total": n_total, "triangles": len(mesh.faces),
-                       "loader": "tolerant", "bvh": a.bvh, "bvh_width": width, "nodes": info["nodes4" if width == 4 else "nodes2"],
+            "config": {"workload": what, "name": workload, "rays_per_gpu": n_local, "rays_total": n_total, "triangles": len(mesh.faces),
+                       "loader": "reference" if workload == "mirror5" else "tolerant",
+                       "bvh": {"fixed": "core/CentroidBVH build, centroid index repaired", "reference": "core/CentroidBVH build as written",
+                               "sah": "library surface-area build"}[a.bvh],
+                       "bvh_width": width, "nodes": info["nodes4" if width == 4 else "nodes2"],
                        "hit_record": "64B RayIntersection" if out_b == 64 else "16B {id,t,u,v}",
                        "frames": frames,
                        "rays": "RayIntersection table resident in HBM" if in_b else "generated in the kernel (rt_trace_primary)",
                        "dispatch_order": "costliest work unit first, from the costs measured two launches earlier" if a.feedback
                        else "image centre first",
-                       "parallelism": f"{world} x frame-parallel" if a.workload != "tiles4k" else f"{world} x interleaved {a.tile}x{a.tile} tiles + RCCL gather"},
-            "roofline": roofline, "cpu_baseline": cpu, "same_launch_on_centroid_tree": centroid,
+                       "parallelism": f"{world} x one process per GPU, " + ("cost-balanced image squares + RCCL gather + device scatter"
+                                                                            if sharded else "frame-parallel")},
+            "roofline": roofline, "cpu_baseline": cpu, "same_launch_on_sah_tree": other,
         }
+        line.update(extra)
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

@@ -202,6 +202,26 @@ int rt_scene_wave_model(const rt_scene *s, const rt_ray_isect *rays_host, size_t
  * (entries) any ray reached. */
 int rt_scene_count_fetches_device(const rt_scene *s, const void *rays_dev, size_t n, uint64_t counts[6]);
 
+/* Traversal cost of every wave-sized work unit (8x8 pixel tile with the image hint, else 64 consecutive records) of
+ * one launch over the given rays: costs_host[k] = loop iterations the wave that traced unit k needed -- the number the
+ * cost-feedback schedule sorts by.  The multi-GPU tile partition balances ranks with it.  costs_host == NULL only
+ * returns the unit count in *nunits.  The _primary form traces the reference's primary-ray table of a width x height
+ * image from `origin` (units = 8x8 tiles, row-major) without needing the table in memory. */
+int rt_scene_unit_costs(const rt_scene *s, const void *rays_dev, size_t n, uint32_t *costs_host, size_t capacity, size_t *nunits);
+int rt_scene_unit_costs_primary(const rt_scene *s, int width, int height, const float origin[3], uint32_t *costs_host,
+                                size_t capacity, size_t *nunits);
+
+/* Framebuffer assembly for image-tile sharding (the reference's only hint of tiling is the commented-out four-offset
+ * NDRange of render_client/img_main.cpp:464-478; it renders straight into one GL texture).  src holds records tile by
+ * tile: tile i of the list is square number tile_ids[i] (row-major over the image cut into tile x tile squares, edge
+ * squares smaller), its records row-major inside the square, starting at record tile_first[i].  Each record
+ * (record_bytes, a multiple of 16) is copied to its pixel of the row-major width x height image dst.  src holds
+ * src_records records; a list entry that names no square of the image, or whose records would run past the end of
+ * src, is skipped.  All pointers are device memory of `device`; enqueued on `stream`. */
+int rt_scatter_tiles(int device, const void *src_dev, size_t src_records, const uint32_t *tile_ids_dev,
+                     const uint32_t *tile_first_dev, size_t ntiles, int tile, int width, int height, size_t record_bytes,
+                     void *dst_dev, void *stream);
+
 /* Diagnostic: runs the instrumented kernel once over n device-resident rays and returns, per wave of
  * 64 rays (or per 8x8 tile with the image hint), records[4*w..4*w+3] = {start, end in 100 MHz ticks,
  * HW_ID register, XCC_ID register}.  capacity is in uint64 elements. */

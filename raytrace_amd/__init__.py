@@ -94,6 +94,9 @@ def _load():
         "rt_trace_primary": (i32, [vp, i32, i32, C.POINTER(C.c_float), vp, vp, vp]),
         "rt_scene_count_fetches": (i32, [vp, vp, sz, sz, C.POINTER(u64), vp]),
         "rt_scene_count_fetches_device": (i32, [vp, vp, sz, C.POINTER(u64)]),
+        "rt_scene_unit_costs": (i32, [vp, vp, sz, vp, sz, C.POINTER(sz)]),
+        "rt_scene_unit_costs_primary": (i32, [vp, i32, i32, C.POINTER(C.c_float), vp, sz, C.POINTER(sz)]),
+        "rt_scatter_tiles": (i32, [i32, vp, sz, vp, vp, sz, i32, i32, i32, sz, vp, vp]),
         "rt_scene_wave_timeline": (i32, [vp, vp, sz, vp, sz]),
         "rt_scene_wave_model": (i32, [vp, vp, sz, u32, u32, sz, i32, C.POINTER(u64)]),
         "rt_debug_tri_batch": (i32, [i32, vp, vp, sz, vp, vp, vp]),
@@ -305,6 +308,23 @@ class Scene:
         _check(lib.rt_scene_count_fetches_device(self._h, _ptr(rays_ptr), n, v))
         return dict(zip(["nodes", "tris", "leaves", "rays_hit", "rays", "max_stack"], [int(x) for x in v]))
 
+    def unit_costs(self, rays_ptr, n):
+        """Per work unit (8x8 tile with the image hint, else 64 records) traversal cost of one launch, as u32."""
+        nu = C.c_size_t()
+        _check(lib.rt_scene_unit_costs(self._h, _ptr(rays_ptr), n, None, 0, C.byref(nu)))
+        out = np.zeros(nu.value, np.uint32)
+        _check(lib.rt_scene_unit_costs(self._h, _ptr(rays_ptr), n, _ptr(out), len(out), C.byref(nu)))
+        return out
+
+    def unit_costs_primary(self, width, height, origin):
+        """The same for the primary-ray table of a width x height image: (tiles_y, tiles_x) u32 of 8x8-tile costs."""
+        o = (C.c_float * 3)(*[float(x) for x in origin])
+        nu = C.c_size_t()
+        _check(lib.rt_scene_unit_costs_primary(self._h, width, height, o, None, 0, C.byref(nu)))
+        out = np.zeros(nu.value, np.uint32)
+        _check(lib.rt_scene_unit_costs_primary(self._h, width, height, o, _ptr(out), len(out), C.byref(nu)))
+        return out.reshape((height + 7) // 8, (width + 7) // 8)
+
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h and lib is not None:
@@ -312,6 +332,12 @@ class Scene:
 
     def __del__(self):
         self.close()
+
+
+def scatter_tiles(device, src_ptr, src_records, tile_ids_ptr, tile_first_ptr, ntiles, tile, width, height, record_bytes, dst_ptr, stream=0):
+    """rt_scatter_tiles on raw device addresses (the caller keeps the index arrays alive until the launch has run)."""
+    _check(lib.rt_scatter_tiles(device, _ptr(src_ptr), src_records, _ptr(tile_ids_ptr), _ptr(tile_first_ptr), ntiles, tile, width, height,
+                                record_bytes, _ptr(dst_ptr), C.c_void_p(stream) if stream else None))
 
 
 def debug_tri_batch(tri, ray, device=0):

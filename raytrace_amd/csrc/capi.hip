@@ -891,6 +891,82 @@ int rt_scene_wave_timeline(const rt_scene *s, const void *rays_dev, size_t n, ui
   return rc;
 }
 
+// One launch that records every work unit's traversal cost (exact, no neighbourhood spreading) and returns the table.
+static int UnitCosts(const rt_scene *s, rt::KernelArgs &a, int mode, uint32_t *costs_host, size_t capacity, size_t *nunits)
+{
+  SetShape(s, a, mode);
+  if (nunits) *nunits = a.ntasks;
+  if (!costs_host) return RT_OK;   // size query
+  if (capacity < a.ntasks) return Fail(RT_ERR_INVALID, "cost buffer too small: " + std::to_string(a.ntasks) + " work units");
+  int rc = CheckStack(s, a, 64u);
+  if (rc != RT_OK) return rc;
+  uint32_t *d_cost = nullptr;
+  RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_cost), static_cast<size_t>(a.ntasks) * sizeof(uint32_t)));
+  hipError_t e = hipMemset(d_cost, 0, static_cast<size_t>(a.ntasks) * sizeof(uint32_t));
+  rc = EnsureStage(&s->d_stage_out, &s->stage_out_bytes, static_cast<size_t>(a.n) * sizeof(rt_hit16));
+  if (e == hipSuccess && rc == RT_OK) {
+    a.hits16 = static_cast<rt_hit16 *>(s->d_stage_out);
+    a.unit_cost = d_cost;
+    a.cost_radius = 0;
+    a.cost_share = 0;
+    e = rt::LaunchClosestHit(a, s->width, s->quant != 0, mode, false, a.ntasks, 64u, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(costs_host, d_cost, static_cast<size_t>(a.ntasks) * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d_cost);
+  if (rc != RT_OK) return rc;
+  if (e != hipSuccess) return FailHip(e, "unit cost launch");
+  return RT_OK;
+}
+
+int rt_scene_unit_costs(const rt_scene *s, const void *rays_dev, size_t n, uint32_t *costs_host, size_t capacity, size_t *nunits)
+{
+  if (!s || !rays_dev) return Fail(RT_ERR_INVALID, "null argument");
+  if (s->device == RT_DEVICE_NONE) return Fail(RT_ERR_DEVICE, "scene was created without a device");
+  if (n == 0 || n > kChunk) return Fail(RT_ERR_INVALID, "ray count out of range for one launch");
+  DeviceGuard guard(s->device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  rt::KernelArgs a;
+  FillArgs(s, a);
+  a.rays = static_cast<const rt_ray_isect *>(rays_dev);
+  a.n = static_cast<uint32_t>(n);
+  return UnitCosts(s, a, rt::kModeIntersect, costs_host, capacity, nunits);
+}
+
+int rt_scene_unit_costs_primary(const rt_scene *s, int width, int height, const float origin[3], uint32_t *costs_host, size_t capacity,
+                                size_t *nunits)
+{
+  if (!s || !origin) return Fail(RT_ERR_INVALID, "null argument");
+  if (s->device == RT_DEVICE_NONE) return Fail(RT_ERR_DEVICE, "scene was created without a device");
+  if (width <= 0 || height <= 0 || static_cast<uint64_t>(width) * static_cast<uint64_t>(height) >= kFeedbackMaxRays)
+    return Fail(RT_ERR_INVALID, "bad image size");
+  DeviceGuard guard(s->device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  rt::KernelArgs a;
+  FillArgs(s, a);
+  a.n = static_cast<uint32_t>(width) * static_cast<uint32_t>(height);
+  a.img_w = static_cast<uint32_t>(width);
+  a.cam[0] = origin[0]; a.cam[1] = origin[1]; a.cam[2] = origin[2];
+  return UnitCosts(s, a, rt::kModePrimary, costs_host, capacity, nunits);
+}
+
+int rt_scatter_tiles(int device, const void *src_dev, size_t src_records, const uint32_t *tile_ids_dev, const uint32_t *tile_first_dev,
+                     size_t ntiles, int tile, int width, int height, size_t record_bytes, void *dst_dev, void *stream)
+{
+  if (!src_dev || !tile_ids_dev || !tile_first_dev || !dst_dev) return Fail(RT_ERR_INVALID, "null argument");
+  if (tile <= 0 || width <= 0 || height <= 0) return Fail(RT_ERR_INVALID, "bad tile or image size");
+  if (record_bytes == 0 || record_bytes % 16u != 0 || record_bytes > 1024u) return Fail(RT_ERR_INVALID, "record size must be a multiple of 16 bytes");
+  if (ntiles == 0) return RT_OK;
+  const uint64_t tiles_total = static_cast<uint64_t>((width + tile - 1) / tile) * static_cast<uint64_t>((height + tile - 1) / tile);
+  if (ntiles > tiles_total) return Fail(RT_ERR_INVALID, "more tiles listed than the image has");
+  if (src_records > 0xFFFFFFFFull) return Fail(RT_ERR_INVALID, "source holds more records than one launch addresses");
+  DeviceGuard guard(device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  RT_HIP(rt::LaunchScatterTiles(src_dev, static_cast<uint32_t>(src_records), tile_ids_dev, tile_first_dev, static_cast<uint32_t>(ntiles), static_cast<uint32_t>(tile),
+                                static_cast<uint32_t>(width), static_cast<uint32_t>(height), static_cast<uint32_t>(record_bytes), dst_dev,
+                                static_cast<hipStream_t>(stream)));
+  return RT_OK;
+}
+
 int rt_debug_tri_batch(int device, const rt_vec3 *tri, const rt_ray *ray, size_t n, int32_t *hit, float *t, rt_vec2 *uv)
 {
   if (!tri || !ray || !hit || !t || !uv) return Fail(RT_ERR_INVALID, "null argument");

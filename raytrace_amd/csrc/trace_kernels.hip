@@ -552,6 +552,29 @@ __global__ void __launch_bounds__(512) BuildOrderKernel(uint32_t *unit_cost, uin
   }
 }
 
+// Tile-major records -> row-major framebuffer.  Tile i of the list covers the pixel block of tile_ids[i] in a W x H image
+// cut into `tile`-sized squares (edge tiles are smaller); its records, row-major inside the block, start at record
+// tile_first[i] of `src`.  One workgroup per tile; a record is `quads` 16-byte pieces, consecutive threads move
+// consecutive pieces, so both sides are read and written in runs of a tile row.
+__global__ void __launch_bounds__(256) ScatterTilesKernel(const uint4 *src, uint32_t src_records, const uint32_t *tile_ids,
+                                                          const uint32_t *tile_first, uint32_t tile, uint32_t img_w, uint32_t img_h,
+                                                          uint32_t quads, uint4 *dst)
+{
+  const uint32_t tiles_x = (img_w + tile - 1u) / tile, tiles_y = (img_h + tile - 1u) / tile;
+  const uint32_t id = tile_ids[blockIdx.x];
+  if (id >= tiles_x * tiles_y) return;   // a list entry that names no square of this image moves nothing
+  const uint32_t ty = id / tiles_x, tx = id - ty * tiles_x;
+  const uint32_t x0 = tx * tile, y0 = ty * tile;
+  const uint32_t w = min(tile, img_w - x0), h = min(tile, img_h - y0);
+  if (static_cast<uint64_t>(tile_first[blockIdx.x]) + static_cast<uint64_t>(w) * h > src_records) return;   // nor one that runs off src
+  const uint32_t row_pieces = w * quads, pieces = row_pieces * h;
+  const uint4 *from = src + static_cast<size_t>(tile_first[blockIdx.x]) * quads;
+  for (uint32_t k = threadIdx.x; k < pieces; k += blockDim.x) {
+    const uint32_t row = k / row_pieces, col = k - row * row_pieces;
+    dst[(static_cast<size_t>(y0 + row) * img_w + x0) * quads + col] = from[k];
+  }
+}
+
 __global__ void TriBatchKernel(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -610,6 +633,15 @@ hipError_t LaunchBuildOrder(uint32_t *unit_cost, uint32_t nunits, uint32_t *orde
   (void)hipGetLastError();
   hipLaunchKernelGGL(BuildOrderKernel, dim3(1), dim3(512), 0, stream, unit_cost, nunits, BuildOrderKeysPerThread(nunits),
                      order);
+  return hipGetLastError();
+}
+
+hipError_t LaunchScatterTiles(const void *src, uint32_t src_records, const uint32_t *tile_ids, const uint32_t *tile_first, uint32_t ntiles,
+                              uint32_t tile, uint32_t img_w, uint32_t img_h, uint32_t record_bytes, void *dst, hipStream_t stream)
+{
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(ScatterTilesKernel, dim3(ntiles), dim3(256), 0, stream, static_cast<const uint4 *>(src), src_records, tile_ids, tile_first, tile,
+                     img_w, img_h, record_bytes / 16u, static_cast<uint4 *>(dst));
   return hipGetLastError();
 }
 

@@ -1,0 +1,83 @@
+"""Image-tile sharding through the HIP path on one GPU: G logical ranks each trace their cost-assigned squares
+(their rays stacked square after square, declared to the library as an image one square wide), the compact
+records land in one gather buffer, rt_scatter_tiles rebuilds the row-major framebuffer on the device, and the
+result must equal the single-launch framebuffer byte for byte."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MODELS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(640, 360, 64), (600, 360, 64), (328, 200, 32)])
+def test_sharded_render_equals_single_launch(rt, gpu, shape):
+    import torch
+    from raytrace_amd.tiles import assign_tiles, balance, rays_of_tiles, tile_costs_from_units, tile_grid
+    W, H, tile = shape
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny.obj"), "tolerant")
+    bvh = rt.BVH(mesh, "fixed")
+    origin = rt.frame_camera(bvh.root_box, W, H)
+    rays = rt.primary_rays(W, H, origin)
+    scene = rt.Scene(mesh, bvh, device=gpu, width=4)
+    try:
+        rays_d = torch.from_numpy(rays).cuda()
+        want = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
+        scene.set_param("image_width", W)
+        scene.intersect_async(rays_d.data_ptr(), W * H, None, want.data_ptr())
+        torch.cuda.synchronize()
+        want_h = want.cpu().numpy()
+        assert int((want_h[:, 0].view(np.uint32) != rt.MISS_ID).sum()) > 1000
+
+        units = scene.unit_costs_primary(W, H, origin)
+        assert units.shape == ((H + 7) // 8, (W + 7) // 8) and units.max() > units.min()
+        # the table of the array form (image hint W) is the same table
+        assert np.array_equal(scene.unit_costs(rays_d.data_ptr(), W * H).reshape(units.shape), units)
+        costs = tile_costs_from_units(units, W, H, tile)
+        tx, ty = tile_grid(W, H, tile)
+        for G in (2, 3, 8):
+            lists = assign_tiles(tx * ty, G, costs)
+            assert balance(lists, costs) < balance(assign_tiles(tx * ty, G, None), costs) + 1e-9
+            gather = torch.full((W * H, 4), -3.0, dtype=torch.float32, device="cuda")
+            ids_all, first_all, base = [], [], 0
+            # a rank's rays are whole squares, each `tile` wide when the width divides evenly: an image one square wide
+            scene.set_param("image_width", tile if W % tile == 0 else 0)
+            for r in range(G):
+                idx, first = rays_of_tiles(W, H, tile, lists[r])
+                mine = torch.from_numpy(rays[idx]).cuda()
+                scene.intersect_async(mine.data_ptr(), len(idx), None, gather.data_ptr() + base * 16)
+                torch.cuda.synchronize()
+                ids_all.append(lists[r].astype(np.uint32))
+                first_all.append(first + np.uint32(base))
+                base += len(idx)
+            assert base == W * H
+            ids_d = torch.from_numpy(np.concatenate(ids_all).astype(np.int32)).cuda()
+            first_d = torch.from_numpy(np.concatenate(first_all).astype(np.int32)).cuda()
+            fb = torch.full((W * H, 4), -5.0, dtype=torch.float32, device="cuda")
+            rt.scatter_tiles(gpu, gather.data_ptr(), W * H, ids_d.data_ptr(), first_d.data_ptr(), len(ids_d), tile, W, H, 16, fb.data_ptr())
+            torch.cuda.synchronize()
+            assert fb.cpu().numpy().tobytes() == want_h.tobytes(), (shape, G)
+        # 64-byte records scatter the same way
+        full = torch.zeros((W * H, 16), dtype=torch.float32, device="cuda")
+        scene.set_param("image_width", W)
+        scene.intersect_async(rays_d.data_ptr(), W * H, full.data_ptr(), None)
+        lists = assign_tiles(tx * ty, 1, costs)
+        idx, first = rays_of_tiles(W, H, tile, lists[0])
+        stacked = full[torch.from_numpy(idx).cuda()].contiguous()
+        fb64 = torch.zeros_like(full)
+        ids_d = torch.from_numpy(lists[0].astype(np.int32)).cuda()       # named: they must outlive the launch
+        first_d = torch.from_numpy(first.astype(np.int32)).cuda()
+        rt.scatter_tiles(gpu, stacked.data_ptr(), W * H, ids_d.data_ptr(), first_d.data_ptr(), len(lists[0]), tile, W, H, 64, fb64.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(fb64.view(torch.int32), full.view(torch.int32))
+        # list entries that name no square, or whose records would run off the source, are skipped, not followed
+        bad_ids = torch.tensor([tx * ty, 0x7FFFFFFF, 0], dtype=torch.int32, device="cuda")
+        bad_first = torch.tensor([0, 0, W * H - 1], dtype=torch.int32, device="cuda")
+        before = fb64.clone()
+        rt.scatter_tiles(gpu, stacked.data_ptr(), W * H, bad_ids.data_ptr(), bad_first.data_ptr(), 3, tile, W, H, 64, fb64.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(fb64.view(torch.int32), before.view(torch.int32))
+    finally:
+        scene.close()

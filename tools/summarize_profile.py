@@ -39,6 +39,12 @@ for k in sorted(acc):
     v = acc[k]
     print(f"{k:36s} {sum(v)/len(v):18.1f}   (n={len(v)})")
 m = {k: sum(v) / len(v) for k, v in acc.items()}
+kd = [v for k, v in dur.items() if KERNEL in k]
+if kd:
+    m["kernel_us_profiled"] = sum(sum(v) for v in kd) / sum(len(v) for v in kd)
+import json as _json
+with open(os.path.join(out, "pmc_entry.json"), "w") as f:   # every counter's per-launch mean: one row of profiles/rNN/pmc_table.json
+    _json.dump({k: round(v, 2) for k, v in m.items()}, f, indent=1, sort_keys=True)
 if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
     rd, wr = m["FETCH_SIZE"] * 1024, m["WRITE_SIZE"] * 1024
     print(f"\nHBM-side bytes per launch: read {rd/1e6:.1f} MB as counted, {2*rd/1e6:.1f} MB with the gfx950 x2 "
