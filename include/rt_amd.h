@@ -125,7 +125,7 @@ int rt_scene_info(const rt_scene *s, uint64_t info[8]);
  *   "block_threads"  64 (default), 128 or 256.
  *   "waves_per_cu"   0..64: cap on resident waves per CU, held by sizing the traversal stack in LDS (default 0 =
  *                    whatever registers and the tree depth allow).
- *   "lds_stack"      8..32 (default 12): traversal-stack entries per lane kept in LDS (8 bytes each); deeper entries
+ *   "lds_stack"      8..32 (default 10): traversal-stack entries per lane kept in LDS (8 bytes each); deeper entries
  *                    spill to the lane's private memory.  Rays of a framed object rarely go deeper than 11.
  *   "persistent"     1: instead of one wave per work unit, "persistent_waves" (1..64, default 24) waves per CU
  *                    stay resident and take units from a global cursor, one wave-level atomic per unit, in

@@ -134,7 +134,7 @@ struct rt_scene {
   mutable hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_sort[2] = {nullptr, nullptr};
   int waves_per_cu = 0;          // optional resident-wave cap per CU, held through the LDS stack size (0 = none)
   int prio_permille = 0;         // with a cost-sorted order: this share (1/1000) of the leading dispatch slots runs at raised priority
-  int lds_stack = 12;            // traversal-stack entries per lane kept in LDS; deeper entries spill to private memory
+  int lds_stack = 10;            // traversal-stack entries per lane kept in LDS; deeper entries spill to private memory
   int persistent = 0;            // 1: a fixed grid of waves pulls work units from a global cursor (one atomic per unit)
   int persistent_waves = 24;     // ... this many waves per CU
   uint32_t *d_cursor = nullptr;  // kCursorSlots cursors, one 128-byte line each, used round-robin by consecutive launches

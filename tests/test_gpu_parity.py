@@ -335,7 +335,7 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
         dict(image_width=W, quantized=0, feedback=1, width=4),
     ]
     defaults = dict(width=2, quantized=1, block_threads=64, image_width=0, leaf_pct=50, persistent=0,
-                    persistent_waves=24, lds_stack=12, centre_first=1, feedback=0, feedback_radius=1, feedback_share=96)
+                    persistent_waves=24, lds_stack=10, centre_first=1, feedback=0, feedback_radius=1, feedback_share=96)
     for cfg in settings:
         for k, v in {**defaults, **cfg}.items():
             scene.set_param(k, v)
