@@ -24,7 +24,7 @@ centroid-index repair (--bvh fixed).  --bvh sah swaps in the library's surface-a
 
 Rank 0 prints ONE JSON line.  `roofline` carries one fraction per resource (hbm: compulsory ray/hit stream
 bytes against the 8 TB/s HBM3E peak; l2: L1-miss requests against the request rate a gather microbenchmark
-reaches on this chip; valu: cycles in which the SIMDs issue vector instructions against all SIMD cycles);
+reaches on this chip; valu: vector instructions x their 2-cycle minimum issue time against all SIMD cycles);
 `frac` is the largest and `bound` names it.  Counter-derived inputs come from committed rocprofv3 passes
 (profiles/rNN/pmc_table.json) and are divided by the launch duration measured live with HIP events.
 `cpu_baseline` times the CPU oracle (brute force over all triangles, the reference's cpu_raycast loop) on a
@@ -373,13 +373,16 @@ def main():
                              "what": "L1-miss read requests (TCP_TCC_READ_REQ) per launch / launch time, against the request "
                                      "rate of a divergent 16-byte gather over an L2-resident table on this chip",
                              "l1_hit_share": round(1.0 - pmc["TCP_TCC_READ_REQ_sum"] / pmc["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)}
-            busy = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / secs         # the counter ticks once per 4 cycles of VALU issue
-            res["valu"] = {"achieved": round(busy / 1e9, 1), "peak": round(SIMDS * CLOCK_HZ / 1e9, 1), "unit": "G SIMD-cycles/s",
-                           "frac": round(busy / (SIMDS * CLOCK_HZ), 4),
-                           "what": "cycles the SIMDs spend issuing vector instructions (SQ_ACTIVE_INST_VALU x 4) per launch / "
-                                   "launch time, against 1024 SIMDs x 2.4 GHz",
+            # a SIMD issues one wave64 vector instruction per 2 cycles at best (32 lanes per cycle)
+            issue = pmc["SQ_INSTS_VALU"] * 2.0 / secs
+            res["valu"] = {"achieved": round(issue / 1e9, 1), "peak": round(SIMDS * CLOCK_HZ / 1e9, 1), "unit": "G SIMD issue cycles/s",
+                           "frac": round(issue / (SIMDS * CLOCK_HZ), 4),
+                           "what": "vector instructions per launch (SQ_INSTS_VALU) x the 2 cycles a wave64 instruction occupies a "
+                                   "32-lane SIMD at best / launch time, against 1024 SIMDs x 2.4 GHz",
                            "instructions_per_wave": round(pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"], 1),
-                           "lane_utilisation": round(pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0), 4)}
+                           "lane_utilisation": round(pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0), 4),
+                           # diagnostic, not a roofline: waves' VALU-active time overlaps within a SIMD, so this can pass 1
+                           "busy_counter_over_simd_cycles": round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / secs / (SIMDS * CLOCK_HZ), 4)}
         bound = max(res, key=lambda k: res[k]["frac"])
         ops = n_node * width * 24 + n_tri * 52     # lane operations the algorithm needs: 24 per box test, 52 per triangle test
         roofline = {
