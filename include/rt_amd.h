@@ -54,6 +54,12 @@ const rt_vec3 *rt_mesh_verts(const rt_mesh *m);
 const rt_face *rt_mesh_faces(const rt_mesh *m);
 const rt_float4 *rt_mesh_normals(const rt_mesh *m);
 const rt_material *rt_mesh_materials(const rt_mesh *m);
+/* `vt` records (core/ObjLoader.cpp:96-118: u, v, optional w in x, y, z) and, three per face, the 0-based `vt` index
+ * of each corner -- the indices the reference parses no further (its lines :178-186 are commented out);
+ * 0xFFFFFFFF where a corner names none.  rt_mesh_face_uvws is NULL for meshes made by rt_mesh_from_arrays. */
+size_t rt_mesh_nuvws(const rt_mesh *m);
+const rt_vec3 *rt_mesh_uvws(const rt_mesh *m);
+const uint32_t *rt_mesh_face_uvws(const rt_mesh *m);
 /* Index of a material name, -1 if absent (does not insert). */
 int rt_mesh_material_index(const rt_mesh *m, const char *name);
 /* Loader log lines ("Quads and ngons not supported, ignoring." ...), newline-joined. */
@@ -83,6 +89,10 @@ void rt_bvh_destroy(rt_bvh *b);
  * rt_ao_rays: `count` seeded incoherent rays numbered first..first+count-1 (no reference
  * counterpart; the divergence stress input). */
 int rt_primary_rays(int W, int H, const float origin[3], rt_ray_isect *out);
+/* The camera matrix of the reference's frame loop (render_client/img_main.cpp:627-660): rotate3 about y by rot_y
+ * and about x by rot_x (core/Affine.h:165-192, its out[1][0] = 0 slip included), multiply (core/Affine.h:194-211),
+ * then the translation; rot_x / rot_y are its cursor / 50 angles.  out[16] is what rt_trace_pass takes as cam. */
+int rt_camera_matrix(float rot_x, float rot_y, const float trans[3], float out[16]);
 int rt_frame_camera(const rt_aabb *root, int W, int H, float origin_out[3]);
 int rt_ao_rays(const rt_mesh *m, const rt_aabb *root, uint64_t seed, size_t first, size_t count, rt_ray_isect *out);
 

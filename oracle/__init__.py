@@ -37,6 +37,10 @@ def _load_oracle():
     lib.oracle_primary_rays.argtypes = [_i32, _i32, C.POINTER(C.c_float), _vp]
     lib.oracle_reflect_ray.restype = None
     lib.oracle_reflect_ray.argtypes = [_vp, _vp]
+    lib.oracle_trace_setup_batch.restype = None
+    lib.oracle_trace_setup_batch.argtypes = [_vp, _sz, C.POINTER(C.c_float), C.c_uint, _vp]
+    lib.oracle_trace_batch.restype = None
+    lib.oracle_trace_batch.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, C.POINTER(C.c_float), C.c_uint, _vp, _vp, _vp, _vp]
     return lib
 
 
@@ -65,6 +69,10 @@ def ref():
         r.ref_bvh_build.argtypes = [_vp, _vp, _sz, _sz, _vp, _sz, C.POINTER(_i32)]
         r.ref_closest_hit.restype = None
         r.ref_closest_hit.argtypes = [_vp, _vp, _sz, _vp, _sz, _vp]
+        r.ref_camera_matrix.restype = None
+        r.ref_camera_matrix.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        r.ref_print_image.restype = _i32
+        r.ref_print_image.argtypes = [_vp, _i32, _i32, C.c_char_p]
         r.ref_min_size_aabb.restype = None
         r.ref_min_size_aabb.argtypes = [_vp]
         _ref = r
@@ -141,6 +149,40 @@ def reflect_rays(records):
     return out
 
 
+def _cam(cam):
+    return (C.c_float * 16)(*[float(x) for x in np.asarray(cam, np.float32).reshape(16)])
+
+
+def trace_setup(records, cam, op):
+    """The rays the `trace` kernel traces for these input records (op 0: camera matrix, op 1: reflection), as
+    (n,16) records with origin and direction filled (render_client/tracekernel.ck:224-265)."""
+    records = np.ascontiguousarray(records, np.float32).reshape(-1, 16)
+    out = np.zeros_like(records)
+    lib.oracle_trace_setup_batch(_p(records), len(records), _cam(cam), op, _p(out))
+    return out
+
+
+def trace_epilogue(mesh, records, cam, op, ids, t, u, v):
+    """Output records (n,16), RGBA pixels (n,4) and a `defined` mask for the given closest hits
+    (render_client/tracekernel.ck:282-286, :373-413)."""
+    records = np.ascontiguousarray(records, np.float32).reshape(-1, 16)
+    n = len(records)
+    hits = np.zeros((n, 4), np.float32)
+    hits[:, 0] = np.asarray(ids, np.uint32).view(np.float32)
+    hits[:, 1], hits[:, 2], hits[:, 3] = t, u, v
+    verts = np.ascontiguousarray(mesh.verts, np.float32)
+    faces = np.ascontiguousarray(mesh.faces, np.uint32)
+    normals = np.ascontiguousarray(mesh.normals, np.float32)
+    mats = np.ascontiguousarray(mesh.materials, np.float32)
+    rec = np.zeros((n, 16), np.float32)
+    rgba = np.zeros((n, 4), np.float32)
+    defined = np.zeros(n, np.int32)
+    lib.oracle_trace_batch(_p(verts), _p(faces), _p(normals) if len(normals) else None, len(normals),
+                           _p(mats) if len(mats) else None, len(mats), _p(records), n, _cam(cam), op, _p(hits), _p(rec), _p(rgba),
+                           _p(defined))
+    return rec, rgba, defined.astype(bool)
+
+
 def ref_closest_hit(verts, faces, rays):
     """Index-order brute force over the REFERENCE's intersect_ray_triangle (single thread)."""
     verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 4)
@@ -149,6 +191,21 @@ def ref_closest_hit(verts, faces, rays):
     hits = np.zeros((len(rays), 4), np.float32)
     ref().ref_closest_hit(_p(verts), _p(faces), len(faces), _p(rays), len(rays), _p(hits))
     return hits[:, 0].view(np.uint32).copy(), hits[:, 1].copy(), hits[:, 2].copy(), hits[:, 3].copy()
+
+
+def ref_camera_matrix(rot_x, rot_y, trans):
+    """core/Affine.h's rotate3 / multiply driven as render_client/img_main.cpp:627-660 drives them: (4,4) f32."""
+    t = (C.c_float * 3)(*[float(x) for x in trans])
+    out = (C.c_float * 16)()
+    ref().ref_camera_matrix(float(rot_x), float(rot_y), t, out)
+    return np.array(list(out), dtype=np.float32).reshape(4, 4)
+
+
+def ref_print_image(bgra, path):
+    """cpu_raycast/bmp.c printImage on an (H,W,4) u8 image, file opened in binary mode."""
+    bgra = np.ascontiguousarray(bgra, np.uint8)
+    if ref().ref_print_image(_p(bgra), bgra.shape[1], bgra.shape[0], os.fsencode(path)) != 0:
+        raise OSError(f"cannot write {path}")
 
 
 def ref_bvh_build(verts, faces):

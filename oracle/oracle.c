@@ -226,3 +226,96 @@ void oracle_reflect_ray(const rt_ray_isect *in, rt_ray *out)
   out->origin.z = in->origin.z + n.z * 0.00001f;
   out->origin.w = 0.f;
 }
+
+/* ---- the `trace` kernel's per-ray setup and hit epilogue, restated -----------------------------------------
+ * render_client/tracekernel.ck:224-265 (setup) and :282-286, :373-413 (output record, pixel), in unfused
+ * float arithmetic, every sum left to right as written there: mult_m_f4 (:182-190) is four-term dots of the
+ * matrix rows with (x,y,z,w); reflect (:101-104) is v - 2*dot4(v,n)*n; the hit point is
+ * (1-u-v)*V[s0] + u*V[s1] + v*V[s2] (:378) and the normal u*N[s4] + v*N[s5] + (1-u-v)*N[s6] (:376).
+ * tracekernel.ck is OpenCL C and cannot run in this container, and OpenCL leaves the rounding and order of its
+ * dot() builtin to the implementation, so no reference-derived vector pins these: PARITY UNPINNED for the
+ * interpolated outputs and the colour.  What this restatement fixes is one definite evaluation order that the
+ * HIP path is held to bit for bit. */
+void oracle_trace_setup(const rt_ray_isect *in, const float cam[16], unsigned op, rt_ray *out)
+{
+  if (op == 1u) {
+    oracle_reflect_ray(in, out);
+    return;
+  }
+  const float o[4] = { in->origin.x, in->origin.y, in->origin.z, 1.f };
+  const float d[4] = { in->direction.x, in->direction.y, in->direction.z, 0.f };
+  float ro[3], rd[3];
+  for (int r = 0; r < 3; ++r) {
+    const float *m = cam + 4 * r;
+    ro[r] = m[0] * o[0] + m[1] * o[1] + m[2] * o[2] + m[3] * o[3];
+    rd[r] = m[0] * d[0] + m[1] * d[1] + m[2] * d[2] + m[3] * d[3];
+  }
+  out->origin.x = ro[0]; out->origin.y = ro[1]; out->origin.z = ro[2]; out->origin.w = 0.f;
+  out->dir.x = rd[0]; out->dir.y = rd[1]; out->dir.z = rd[2]; out->dir.w = 0.f;
+}
+
+/* Output record and RGBA pixel of one ray.  `ray` is the ray that was traced (after setup), `hit` its closest
+ * hit.  Miss: origin and normal := the input record's origin and direction, uv = 0, id = ~0 (:282-286), pixel
+ * (0,0,0,0); `direction` is left unwritten by the reference and carries the input direction here.  Returns 0 when
+ * the face names a normal index outside `normals` (the reference reads out of bounds there; the HIP path
+ * substitutes a geometric normal, which this restatement does not define), else 1. */
+int oracle_trace_epilogue(const rt_vec3 *verts, const rt_face *faces, const rt_float4 *normals, size_t nnormals,
+                          const rt_material *mats, size_t nmats, const rt_ray_isect *in, const rt_ray *ray,
+                          const rt_hit16 *hit, rt_ray_isect *out, float rgba[4])
+{
+  memset(out, 0, sizeof *out);
+  out->origin = in->origin;
+  out->direction = in->direction;
+  out->normal = in->direction;
+  out->uv.u = 0.f; out->uv.v = 0.f;
+  out->triangle_id = RT_MISS_ID;
+  memcpy(&out->t_bits, &hit->t, sizeof(float));
+  rgba[0] = rgba[1] = rgba[2] = rgba[3] = 0.f;
+  if (hit->triangle_id == RT_MISS_ID) return 1;
+  const uint32_t *s = faces[hit->triangle_id].s;
+  if (s[4] >= nnormals || s[5] >= nnormals || s[6] >= nnormals) return 0;
+  const float u = hit->u, v = hit->v, w = 1.f - u - v;
+  const rt_vec3 *v0 = &verts[s[0]], *v1 = &verts[s[1]], *v2 = &verts[s[2]];
+  const rt_float4 *n0 = &normals[s[4]], *n1 = &normals[s[5]], *n2 = &normals[s[6]];
+  out->origin.x = w * v0->x + u * v1->x + v * v2->x;
+  out->origin.y = w * v0->y + u * v1->y + v * v2->y;
+  out->origin.z = w * v0->z + u * v1->z + v * v2->z;
+  out->origin.w = 1.f;
+  const float nx = u * n0->x + v * n1->x + w * n2->x;
+  const float ny = u * n0->y + v * n1->y + w * n2->y;
+  const float nz = u * n0->z + v * n1->z + w * n2->z;
+  out->normal.x = nx; out->normal.y = ny; out->normal.z = nz; out->normal.w = 0.f;
+  out->direction.x = ray->dir.x; out->direction.y = ray->dir.y; out->direction.z = ray->dir.z; out->direction.w = 0.f;
+  out->uv.u = u; out->uv.v = v;
+  out->triangle_id = hit->triangle_id;
+  if (nmats) {
+    const rt_material *m = &mats[s[3] < nmats ? s[3] : 0u];
+    const float k = fabsf(nx * ray->dir.x + ny * ray->dir.y + nz * ray->dir.z);
+    rgba[0] = k * m->color.x; rgba[1] = k * m->color.y; rgba[2] = k * m->color.z; rgba[3] = m->Rf;
+  }
+  return 1;
+}
+
+/* Batch form: n records; rays_out[i] = the traced ray, rec_out[i], rgba_out[4*i..], defined[i] as returned above. */
+void oracle_trace_batch(const rt_vec3 *verts, const rt_face *faces, const rt_float4 *normals, size_t nnormals,
+                        const rt_material *mats, size_t nmats, const rt_ray_isect *in, size_t n, const float cam[16],
+                        unsigned op, const rt_hit16 *hits, rt_ray_isect *rec_out, float *rgba_out, int32_t *defined)
+{
+  for (size_t i = 0; i < n; ++i) {
+    rt_ray ray;
+    oracle_trace_setup(&in[i], cam, op, &ray);
+    defined[i] = oracle_trace_epilogue(verts, faces, normals, nnormals, mats, nmats, &in[i], &ray, &hits[i], &rec_out[i], rgba_out + 4 * i);
+  }
+}
+
+/* rays_out[i] (as a 64-byte record: origin, direction) = the ray the kernel traces for record i. */
+void oracle_trace_setup_batch(const rt_ray_isect *in, size_t n, const float cam[16], unsigned op, rt_ray_isect *rays_out)
+{
+  for (size_t i = 0; i < n; ++i) {
+    rt_ray ray;
+    oracle_trace_setup(&in[i], cam, op, &ray);
+    memset(&rays_out[i], 0, sizeof rays_out[i]);
+    rays_out[i].origin.x = ray.origin.x; rays_out[i].origin.y = ray.origin.y; rays_out[i].origin.z = ray.origin.z;
+    rays_out[i].direction.x = ray.dir.x; rays_out[i].direction.y = ray.dir.y; rays_out[i].direction.z = ray.dir.z;
+  }
+}

@@ -81,3 +81,37 @@ void ref_centroid(const vec3 *tri3, vec3 *c) { Centroid(reinterpret_cast<Tri con
 int ref_point_in_aabb(const vec3 *p, const AABB *bb) { return PointInAABB(p, bb) ? 1 : 0; }
 
 }
+
+// ---- core/Affine.h (header-only): the camera matrix as render_client/img_main.cpp:627-660 builds it ------------
+#include "Affine.h"
+extern "C" void ref_camera_matrix(float rot_x, float rot_y, const float trans_xyz[3], float out[16])
+{
+  float axisy[4]{ 0, 1, 0, 0 };
+  float axisx[4]{ 1, 0, 0, 0 };
+  float roty[4][4]{ 0 };
+  float rotx[4][4]{ 0 };
+  fmat4x4 rotation, cam_matrix;
+  rotate3(roty, axisy, rot_y);
+  rotate3(rotx, axisx, rot_x);
+  multiply(roty, rotx, rotation);
+  float trans[4][4] = {
+    1, 0, 0, trans_xyz[0],
+    0, 1, 0, trans_xyz[1],
+    0, 0, 1, trans_xyz[2],
+    0, 0, 0, 1
+  };
+  multiply(trans, rotation, cam_matrix);
+  memcpy(out, cam_matrix, sizeof cam_matrix);
+}
+
+// ---- cpu_raycast/bmp.c (plain C, compiled where it lies): printImage into a file opened in binary mode ---------
+typedef unsigned char ref_pixel[4];
+extern "C" void printImage(ref_pixel *data, int width, int height, FILE *file);
+extern "C" int ref_print_image(const unsigned char *bgra, int width, int height, const char *path)
+{
+  FILE *f = fopen(path, "wb");
+  if (!f) return -1;
+  printImage((ref_pixel *)bgra, width, height, f);
+  fclose(f);
+  return 0;
+}

@@ -72,6 +72,7 @@ def _load():
         "rt_mesh_nnormals": (sz, [vp]), "rt_mesh_nmaterials": (sz, [vp]),
         "rt_mesh_verts": (vp, [vp]), "rt_mesh_faces": (vp, [vp]),
         "rt_mesh_normals": (vp, [vp]), "rt_mesh_materials": (vp, [vp]),
+        "rt_mesh_nuvws": (sz, [vp]), "rt_mesh_uvws": (vp, [vp]), "rt_mesh_face_uvws": (vp, [vp]),
         "rt_mesh_material_index": (i32, [vp, C.c_char_p]),
         "rt_mesh_log": (C.c_char_p, [vp]),
         "rt_mesh_destroy": (None, [vp]),
@@ -81,6 +82,7 @@ def _load():
         "rt_bvh_fallback_splits": (i32, [vp]),
         "rt_bvh_destroy": (None, [vp]),
         "rt_primary_rays": (i32, [i32, i32, C.POINTER(C.c_float), vp]),
+        "rt_camera_matrix": (i32, [C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "rt_frame_camera": (i32, [vp, i32, i32, C.POINTER(C.c_float)]),
         "rt_ao_rays": (i32, [vp, vp, u64, sz, sz, vp]),
         "rt_scene_create": (i32, [vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, i32, u32, C.POINTER(vp)]),
@@ -144,6 +146,9 @@ class Mesh:
         self.faces = _copy(lib.rt_mesh_faces(handle), lib.rt_mesh_ntris(handle), 8, np.uint32)
         self.normals = _copy(lib.rt_mesh_normals(handle), lib.rt_mesh_nnormals(handle), 4, np.float32)
         self.materials = _copy(lib.rt_mesh_materials(handle), lib.rt_mesh_nmaterials(handle), 12, np.float32)
+        self.uvws = _copy(lib.rt_mesh_uvws(handle), lib.rt_mesh_nuvws(handle), 4, np.float32)
+        fu = lib.rt_mesh_face_uvws(handle)
+        self.face_uvws = _copy(fu, len(self.faces), 3, np.uint32) if fu else np.zeros((0, 3), np.uint32)
         self.log = lib.rt_mesh_log(handle).decode(errors="replace").splitlines()
 
     @classmethod
@@ -203,6 +208,14 @@ def primary_rays(width, height, origin):
     o = (C.c_float * 3)(*[float(x) for x in origin])
     _check(lib.rt_primary_rays(width, height, o, _ptr(out)))
     return out
+
+
+def camera_matrix(rot_x, rot_y, trans):
+    """(4,4) f32 camera matrix of the reference's frame loop (render_client/img_main.cpp:627-660)."""
+    t = (C.c_float * 3)(*[float(x) for x in trans])
+    out = (C.c_float * 16)()
+    _check(lib.rt_camera_matrix(float(rot_x), float(rot_y), t, out))
+    return np.array(list(out), dtype=np.float32).reshape(4, 4)
 
 
 def frame_camera(root_box, width, height):

@@ -425,6 +425,9 @@ const rt_vec3 *rt_mesh_verts(const rt_mesh *m) { return m ? m->mesh.verts.data()
 const rt_face *rt_mesh_faces(const rt_mesh *m) { return m ? m->mesh.faces.data() : nullptr; }
 const rt_float4 *rt_mesh_normals(const rt_mesh *m) { return m ? m->mesh.normals.data() : nullptr; }
 const rt_material *rt_mesh_materials(const rt_mesh *m) { return m ? m->mesh.mtllib.materials.data() : nullptr; }
+size_t rt_mesh_nuvws(const rt_mesh *m) { return m ? m->mesh.uvws.size() : 0; }
+const rt_vec3 *rt_mesh_uvws(const rt_mesh *m) { return m ? m->mesh.uvws.data() : nullptr; }
+const uint32_t *rt_mesh_face_uvws(const rt_mesh *m) { return m && !m->mesh.face_uvws.empty() ? m->mesh.face_uvws.data() : nullptr; }
 
 int rt_mesh_material_index(const rt_mesh *m, const char *name)
 {
@@ -481,6 +484,13 @@ int rt_primary_rays(int W, int H, const float origin[3], rt_ray_isect *out)
 {
   if (W <= 0 || H <= 0 || !origin || !out) return Fail(RT_ERR_INVALID, "bad primary-ray arguments");
   rt::PrimaryRays(W, H, origin, out);
+  return RT_OK;
+}
+
+int rt_camera_matrix(float rot_x, float rot_y, const float trans[3], float out[16])
+{
+  if (!trans || !out) return Fail(RT_ERR_INVALID, "null argument");
+  rt::CameraMatrix(rot_x, rot_y, trans, out);
   return RT_OK;
 }
 

@@ -39,6 +39,9 @@ struct Mesh {
   std::vector<rt_vec3> verts;
   std::vector<rt_float4> normals;
   std::vector<rt_face> faces;
+  std::vector<rt_vec3> uvws;          // `vt` records as the reference parses them (core/ObjLoader.cpp:96-118): u, v, optional w
+  std::vector<uint32_t> face_uvws;    // 3 per face: 0-based `vt` index of each corner ("v/vt/vn"), 0xFFFFFFFF where absent --
+                                      // the indices the reference leaves commented out (core/ObjLoader.cpp:178-186)
   MtlLib mtllib;
   std::vector<std::string> log;  // the messages the reference printf()s
 };
@@ -75,6 +78,13 @@ void CentroidBVHBuild(CentroidBVH *bvh, rt_face const *triangles, rt_vec3 const 
                       size_t vertcount, BvhMode mode);
 // Same output format, topology from the binned surface-area heuristic (sah_bvh.cpp).
 void SahBVHBuild(CentroidBVH *bvh, rt_face const *triangles, rt_vec3 const *verts, size_t tricount, size_t vertcount);
+
+// ---- camera matrix ----------------------------------------------------------
+// The matrix the reference's frame loop uploads each frame (render_client/img_main.cpp:627-660): rotations about y
+// and x built by rotate3 (core/Affine.h:165-192, including its out[1][0] = 0 slip), combined by multiply
+// (core/Affine.h:194-211), then the translation.  rot_x / rot_y are the angles it derives from the cursor
+// (cursor / 50); out is the 16 floats handed to the kernel, whose rows are dotted with (x,y,z,w).
+void CameraMatrix(float rot_x, float rot_y, const float trans[3], float out[16]);
 
 // ---- ray generators ---------------------------------------------------------
 // Primary-ray table of render_client/img_main.cpp:253-267 for a W x H image;

@@ -5,7 +5,7 @@
 // core/MtlLib.cpp:3-12.  Record grammar:
 //   v x y z            -> vertex (x,y,z,1); fewer than 4 tokens -> (0,0,0,1)
 //   vn x y z           -> normal (x,y,z,0); fewer than 4 tokens -> (1,0,0,0)
-//   vt ...             -> parsed by the reference, never used; skipped here
+//   vt u v [w]         -> texture coordinate; kept, with the per-corner indices the reference leaves commented out
 //   f a b c            -> exactly 4 tokens, each "v", "v/vt" or "v/vt/vn"; 1-based
 //   mtllib file        -> load materials from folder + file
 //   usemtl name        -> current material index (unknown name -> 0)
@@ -79,6 +79,7 @@ struct Corner {
   explicit Corner(std::string const &s) { SplitString(s, '/', f, true); }
   bool HasVertex() const { return !f.empty() && !f[0].empty(); }
   bool HasNormal() const { return f.size() > 2 && !f[2].empty(); }
+  bool HasTexcoord() const { return f.size() > 1 && !f[1].empty(); }
 };
 
 }  // namespace
@@ -130,6 +131,8 @@ void LoadObj(std::istream &file, Mesh &mesh, std::string const &folder, LoaderMo
   std::vector<rt_vec3> vertices;
   std::vector<rt_float4> normals;
   std::vector<rt_face> faces;
+  std::vector<rt_vec3> uvws;
+  std::vector<uint32_t> face_uvws;
   int curr_mat_index = 0;
   LineReader rd{file, {}, {}, {}, mode == kLoaderReference};
 
@@ -158,6 +161,19 @@ void LoadObj(std::istream &file, Mesh &mesh, std::string const &folder, LoaderMo
         n.z = ToFloat(rd.tok[3]);
       }
       normals.push_back(n);
+    } else if (ty == "vt") {
+      // core/ObjLoader.cpp:96-118: fewer than two values -> (0,0); a third value is optional (the reference leaves
+      // z unset without one; 0 here)
+      rd.Tokens();
+      rt_vec3 uvw{0, 0, 0, 0};
+      if (rd.tok.size() < 3) {
+        mesh.log.push_back("incomplete texture coordinate record, using (0,0)");
+      } else {
+        uvw.x = ToFloat(rd.tok[1]);
+        uvw.y = ToFloat(rd.tok[2]);
+        if (rd.tok.size() > 3) uvw.z = ToFloat(rd.tok[3]);
+      }
+      uvws.push_back(uvw);
     } else if (ty == "f") {
       rd.Tokens();
       if (rd.tok.size() < 4) {
@@ -190,6 +206,10 @@ void LoadObj(std::istream &file, Mesh &mesh, std::string const &folder, LoaderMo
             face.s[6] = index(c2.f[2], normals.size());
           }
           faces.push_back(face);
+          const bool has_uv = c0.HasTexcoord() && c1.HasTexcoord() && c2.HasTexcoord();
+          face_uvws.push_back(has_uv ? index(c0.f[1], uvws.size()) : 0xFFFFFFFFu);
+          face_uvws.push_back(has_uv ? index(c1.f[1], uvws.size()) : 0xFFFFFFFFu);
+          face_uvws.push_back(has_uv ? index(c2.f[1], uvws.size()) : 0xFFFFFFFFu);
         }
       }
     } else if (ty == "mtllib") {
@@ -202,11 +222,13 @@ void LoadObj(std::istream &file, Mesh &mesh, std::string const &folder, LoaderMo
       rd.Tokens();
       curr_mat_index = mesh.mtllib.MaterialIndex(rd.tok.size() > 1 ? rd.tok[1] : std::string());
     }
-    // '#', 'vt' and every other record type carry nothing this path uses.
+    // '#' and every other record type carry nothing this path uses.
   }
   mesh.verts = std::move(vertices);
   mesh.faces = std::move(faces);
   mesh.normals = std::move(normals);
+  mesh.uvws = std::move(uvws);
+  mesh.face_uvws = std::move(face_uvws);
 }
 
 bool LoadObjFile(std::string const &path, Mesh &mesh, LoaderMode mode)

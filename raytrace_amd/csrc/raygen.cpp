@@ -111,4 +111,70 @@ void AoRays(rt_vec3 const *verts, rt_face const *faces, size_t ntris, rt_aabb co
   for (auto &th : pool) th.join();
 }
 
+namespace {
+
+// core/Affine.h:41-48: length over all four components, the fourth component passed through undivided.
+void Normalize4(const float in[4], float out[4])
+{
+  const float len = std::sqrt(in[0] * in[0] + in[1] * in[1] + in[2] * in[2] + in[3] * in[3]);
+  out[0] = in[0] / len;
+  out[1] = in[1] / len;
+  out[2] = in[2] / len;
+  out[3] = in[3];
+}
+
+// core/Affine.h:165-192.  `out` arrives zeroed (the caller's `float roty[4][4]{ 0 }`, img_main.cpp:629-630).  The
+// second assignment to out[1][0] -- meant for out[1][3] -- zeroes the element the line three above it computed;
+// it is restated, not repaired: the matrices the reference uploads have that zero in them.
+void Rotate3(float out[4][4], const float vec[4], float angle)
+{
+  const float cos_a = static_cast<float>(std::cos(static_cast<double>(angle)));
+  const float sin_a = static_cast<float>(std::sin(static_cast<double>(angle)));
+  float v[4];
+  Normalize4(vec, v);
+  out[0][0] = cos_a + v[0] * v[0] * (1 - cos_a);
+  out[0][1] = v[0] * v[1] * (1 - cos_a) - v[2] * sin_a;
+  out[0][2] = v[0] * v[2] * (1 - cos_a) + v[1] * sin_a;
+  out[0][3] = 0;
+  out[1][0] = v[0] * v[1] * (1 - cos_a) + v[2] * sin_a;
+  out[1][1] = cos_a + v[1] * v[1] * (1 - cos_a);
+  out[1][2] = v[1] * v[2] * (1 - cos_a) - v[0] * sin_a;
+  out[1][0] = 0;
+  out[2][0] = v[0] * v[2] * (1 - cos_a) - v[1] * sin_a;
+  out[2][1] = v[1] * v[2] * (1 - cos_a) + v[0] * sin_a;
+  out[2][2] = cos_a + v[2] * v[2] * (1 - cos_a);
+  out[2][3] = 0;
+  out[3][0] = 0;
+  out[3][1] = 0;
+  out[3][2] = 0;
+  out[3][3] = 1;
+}
+
+// core/Affine.h:194-211 for 4x4 operands: out[j][i] = sum_k a[k][i] * b[j][k], accumulated from zero in k order.
+void Multiply4(const float a[4][4], const float b[4][4], float out[4][4])
+{
+  float tmp_m[4][4];
+  for (unsigned i = 0; i < 4; ++i)
+    for (unsigned j = 0; j < 4; ++j) {
+      float tmp = 0;
+      for (unsigned k = 0; k < 4; ++k) tmp += a[k][i] * b[j][k];
+      tmp_m[j][i] = tmp;
+    }
+  std::memcpy(out, tmp_m, sizeof tmp_m);
+}
+
+}  // namespace
+
+void CameraMatrix(float rot_x, float rot_y, const float trans_xyz[3], float out[16])
+{
+  const float axisy[4] = {0, 1, 0, 0}, axisx[4] = {1, 0, 0, 0};
+  float roty[4][4] = {{0}}, rotx[4][4] = {{0}}, rotation[4][4], cam[4][4];
+  Rotate3(roty, axisy, rot_y);
+  Rotate3(rotx, axisx, rot_x);
+  Multiply4(roty, rotx, rotation);
+  const float trans[4][4] = {{1, 0, 0, trans_xyz[0]}, {0, 1, 0, trans_xyz[1]}, {0, 0, 1, trans_xyz[2]}, {0, 0, 0, 1}};
+  Multiply4(trans, rotation, cam);
+  std::memcpy(out, cam, sizeof cam);
+}
+
 }  // namespace rt

@@ -1,10 +1,11 @@
 """The full `trace` step (render_client/tracekernel.ck:192-414) through rt_trace_pass: camera
 transform (op 0), reflection regeneration (op 1), output record and RGBA32F pixel.
 
-Ray setup is restated in float32 numpy in the same left-to-right unfused order the kernel uses, so
-hit ids and t/u/v stay bit-exact against the brute-force oracle; the colour and the interpolated
-outputs are held to 1e-5 relative (their reference expressions are OpenCL builtins whose rounding is
-implementation-defined)."""
+Ray setup, output record and pixel are compared BIT FOR BIT with oracle.c's restatement of
+render_client/tracekernel.ck:224-265, :282-286, :373-413 (unfused float, sums left to right as written
+there).  That restatement is parity-unpinned for the interpolated outputs and the colour: the kernel is
+OpenCL C, cannot run here, and leaves the rounding of dot() to the implementation; ids and t/u/v are pinned
+through the brute-force oracle as everywhere else."""
 import os
 
 import numpy as np
@@ -15,10 +16,6 @@ from conftest import MODELS, bits, framed_primary
 pytestmark = pytest.mark.gpu
 REL = 1e-5
 f32 = np.float32
-
-
-def dot4(m, v):
-    return ((m[0] * v[:, 0] + m[1] * v[:, 1]) + m[2] * v[:, 2]) + m[3] * v[:, 3]
 
 
 def run_pass(scene, rays_in, cam, op):
@@ -47,13 +44,8 @@ def test_primary_then_reflection_pass(rt, oracle, gpu, width):
     rays = rt.primary_rays(W, H, (0, 0, 0))
     out0, rgba0 = run_pass(scene, rays, cam, 0)
 
-    # ---- op 0: expected world-space rays, float32, same operation order -------------
-    o4 = rays[:, 0:4].copy(); o4[:, 3] = 1
-    d4 = rays[:, 4:8].copy(); d4[:, 3] = 0
-    world = np.zeros_like(rays)
-    for k in range(3):
-        world[:, k] = dot4(cam[k], o4)
-        world[:, 4 + k] = dot4(cam[k], d4)
+    # ---- op 0: the rays the kernel must have traced, then the whole output record and pixel ----------------
+    world = oracle.trace_setup(rays, cam, 0)
     oid, ot, ou, ov = oracle.closest_hit(mesh.verts, mesh.faces, world)
     ids, t, u, v = rt.hit_fields(out0)
     assert np.array_equal(ids, oid)
@@ -61,27 +53,15 @@ def test_primary_then_reflection_pass(rt, oracle, gpu, width):
     assert 0.05 < h.mean() < 0.95
     for a, b in ((t, ot), (u, ou), (v, ov)):
         assert np.array_equal(bits(a[h]), bits(b[h]))
-    assert np.array_equal(bits(out0[h, 4:7]), bits(world[h, 4:7]))          # direction = transformed dir
-    # miss: record defaults (origin, normal := input direction) and a (0,0,0,0) pixel
-    assert np.array_equal(bits(out0[~h, 0:4]), bits(rays[~h, 0:4])) and np.array_equal(bits(out0[~h, 8:12]), bits(rays[~h, 4:8]))
-    assert np.all(rgba0[~h] == 0)
-    # hit: colour = |n.d| * material.color, alpha = material.Rf
-    f = mesh.faces[ids[h]]
-    n = out0[h, 8:11].astype(np.float64)
-    k = np.abs(np.einsum("ij,ij->i", n, world[h, 4:7].astype(np.float64)))
-    want = np.concatenate([k[:, None] * mesh.materials[f[:, 3], 0:3], mesh.materials[f[:, 3], 9:10]], axis=1)
-    assert np.abs(rgba0[h] - want).max() <= REL * max(1.0, np.abs(want).max())
-    N = mesh.normals.astype(np.float64)
-    uu, vv = u[h].astype(np.float64)[:, None], v[h].astype(np.float64)[:, None]
-    nn = uu * N[f[:, 4], :3] + vv * N[f[:, 5], :3] + (1 - uu - vv) * N[f[:, 6], :3]
-    assert np.abs(n - nn).max() <= REL
+    want_rec, want_rgba, defined = oracle.trace_epilogue(mesh, rays, cam, 0, oid, ot, ou, ov)
+    assert defined.all()                                   # every face of this model carries vertex normals
+    assert np.array_equal(bits(out0), bits(want_rec))      # hit point, normal, direction, uv, id, t; miss defaults
+    assert np.array_equal(bits(rgba0), bits(want_rgba))    # |n.d| * material.color, alpha = material.Rf; (0,0,0,0) on a miss
+    assert np.all(rgba0[~h] == 0) and rgba0[h, :3].max() > 0
 
     # ---- op 1: reflect the pass-0 records --------------------------------------------
     out1, rgba1 = run_pass(scene, out0, cam, 1)
-    refl = oracle.reflect_rays(out0)
-    rec = np.zeros_like(out0)
-    rec[:, 0:3] = refl[:, 0:3]
-    rec[:, 4:7] = refl[:, 4:7]
+    rec = oracle.trace_setup(out0, cam, 1)
     rid, rtt, ru, rv = oracle.closest_hit(mesh.verts, mesh.faces, rec)
     ids1, t1, u1, v1 = rt.hit_fields(out1)
     live = h
@@ -91,7 +71,40 @@ def test_primary_then_reflection_pass(rt, oracle, gpu, width):
     assert hh.sum() > 0
     for a, b in ((t1, rtt), (u1, ru), (v1, rv)):
         assert np.array_equal(bits(a[hh]), bits(b[hh]))
-    assert np.array_equal(bits(out1[hh, 4:7]), bits(refl[hh, 4:7]))
+    want_rec1, want_rgba1, defined1 = oracle.trace_epilogue(mesh, out0, cam, 1, rid, rtt, ru, rv)
+    assert defined1.all()
+    assert np.array_equal(bits(out1[live]), bits(want_rec1[live]))
+    assert np.array_equal(bits(rgba1[live]), bits(want_rgba1[live]))
+    # a terminated record passes through: origin, direction and normal as they came in, id = miss
+    assert np.array_equal(bits(out1[~live, 0:12]), bits(out0[~live, 0:12]))
+
+
+def test_frame_loop_camera_matrices_drive_the_primary_pass(rt, oracle, gpu):
+    """op 0 fed the matrices the reference's frame loop produces (rt_camera_matrix = core/Affine.h rotate3 /
+    multiply as render_client/img_main.cpp:627-660 uses them): a camera-space ray table, the eye placed by the
+    translation, the view turned by the cursor angles.  Every frame's ids and t/u/v equal the oracle's."""
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "teapot.obj"), "reference")
+    bvh = rt.BVH(mesh, "fixed")
+    scene = rt.Scene(mesh, bvh, device=gpu, width=4)
+    W, H = 160, 100
+    scene.set_param("image_width", W)
+    rays = rt.primary_rays(W, H, (0, 0, 0))
+    eye = rt.frame_camera(bvh.root_box, W, H)
+    seen = set()
+    for rx, ry in ((0.0, 0.0), (0.02, -0.05), (-0.04, 0.08), (0.0, 0.3)):
+        cam = rt.camera_matrix(rx, ry, eye)
+        out, rgba = run_pass(scene, rays, cam, 0)
+        world = oracle.trace_setup(rays, cam, 0)
+        oid, ot, ou, ov = oracle.closest_hit(mesh.verts, mesh.faces, world)
+        ids, t, u, v = rt.hit_fields(out)
+        assert np.array_equal(ids, oid), (rx, ry)
+        h = oid != rt.MISS_ID
+        for a, b in ((t, ot), (u, ou), (v, ov)):
+            assert np.array_equal(bits(a[h]), bits(b[h]))
+        want_rec, want_rgba, defined = oracle.trace_epilogue(mesh, rays, cam, 0, oid, ot, ou, ov)
+        assert np.array_equal(bits(out[defined]), bits(want_rec[defined]))
+        seen.add(int(h.sum()))
+    assert len(seen) >= 3 and max(seen) > 1000       # the view really changed between frames
 
 
 def test_identity_camera_equals_plain_intersection(rt, gpu):
@@ -156,18 +169,7 @@ def test_five_pass_bounce_chain_full_size(rt, oracle, gpu, model):
         torch.cuda.synchronize()
         out = bufs[(k + 1) & 1].cpu().numpy()
         ids, t, u, v = rt.hit_fields(out)
-        if k == 0:
-            o4 = prev[sel, 0:4].copy(); o4[:, 3] = 1
-            d4 = prev[sel, 4:8].copy(); d4[:, 3] = 0
-            want_rays = np.zeros((len(sel), 16), f32)
-            for ax in range(3):
-                want_rays[:, ax] = dot4(cam[ax], o4)
-                want_rays[:, 4 + ax] = dot4(cam[ax], d4)
-        else:
-            refl = oracle.reflect_rays(prev[sel])
-            want_rays = np.zeros((len(sel), 16), f32)
-            want_rays[:, 0:3] = refl[:, 0:3]
-            want_rays[:, 4:7] = refl[:, 4:7]
+        want_rays = oracle.trace_setup(prev[sel], cam, 0 if k == 0 else 1)
         oid, ot, ou, ov = oracle.closest_hit(mesh.verts, mesh.faces, want_rays)
         live = alive[sel]
         assert np.array_equal(ids[sel][live], oid[live]), f"pass {k}"
@@ -175,6 +177,10 @@ def test_five_pass_bounce_chain_full_size(rt, oracle, gpu, model):
         hh = live & (oid != rt.MISS_ID)
         for a, b in ((t, ot), (u, ou), (v, ov)):
             assert np.array_equal(bits(a[sel][hh]), bits(b[hh])), f"pass {k}"
+        want_rec, want_rgba, defined = oracle.trace_epilogue(mesh, prev[sel], cam, 0 if k == 0 else 1, oid, ot, ou, ov)
+        ok = live & defined
+        assert np.array_equal(bits(out[sel][ok]), bits(want_rec[ok])), f"pass {k}: output record"
+        assert np.array_equal(bits(rgba.cpu().numpy()[sel][ok]), bits(want_rgba[ok])), f"pass {k}: pixel"
         alive &= ids != rt.MISS_ID
         hits_per_pass.append(int(alive.sum()))
         prev = out

@@ -109,3 +109,26 @@ def test_extended_loader_fans_polygons_and_resolves_relative_indices(rt, tmp_pat
     bvh = rt.BVH(wheel_e, "sah")
     sc = rt.Scene(wheel_e, bvh, device=-1)     # the fanned mesh flattens
     sc.close()
+
+
+def test_texture_coordinates_and_their_face_indices(rt, tmp_path):
+    """`vt` records as core/ObjLoader.cpp:96-118 parses them, plus the per-corner indices it leaves commented out
+    (:178-186): 0-based, 0xFFFFFFFF where a face names none."""
+    p = tmp_path / "uv.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\n"
+                 "vt 0.25 0.5\nvt 1 0 0.75\nvt 0.5\nvt 0 1\n"
+                 "vn 0 0 1\n"
+                 "f 1/1/1 2/2/1 3/4/1\n"      # v/vt/vn
+                 "f 2/2 4/3 3/1\n"            # v/vt
+                 "f 1//1 2//1 4//1\n"         # no vt
+                 "f 1 2 3\n")
+    for mode in ("reference", "tolerant", "extended"):
+        m = rt.Mesh.load_obj(str(p), mode)
+        assert m.uvws.shape == (4, 4)
+        assert np.allclose(m.uvws[:, :3], [[0.25, 0.5, 0], [1, 0, 0.75], [0, 0, 0], [0, 1, 0]])
+        assert "incomplete texture coordinate record, using (0,0)" in m.log
+        miss = 0xFFFFFFFF
+        assert m.face_uvws.tolist() == [[0, 1, 3], [1, 2, 0], [miss] * 3, [miss] * 3]
+        assert m.faces[:, :3].tolist() == [[0, 1, 2], [1, 3, 2], [0, 1, 3], [0, 1, 2]]
+    teapot = rt.Mesh.load_obj(os.path.join(MODELS, "teapot.obj"), "reference")
+    assert len(teapot.face_uvws) == len(teapot.faces)

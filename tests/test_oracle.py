@@ -137,3 +137,32 @@ def test_brute_force_tie_goes_to_lowest_index_and_second_t(oracle):
     if oracle.have_ref():
         rid, rtt, ru, rv = oracle.ref_closest_hit(verts, faces, rays)
         assert rid.tolist() == [0, 1] and np.array_equal(bits(rtt), bits(t))
+
+
+def test_camera_matrix_is_the_reference_frame_loops(rt, oracle):
+    """rt_camera_matrix against core/Affine.h's own rotate3 / multiply (header-only templates instantiated in
+    oracle/_ref) driven as render_client/img_main.cpp:627-660 drives them: all 16 floats, bit for bit."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    rng = np.random.default_rng(11)
+    cases = [(0.0, 0.0, (0, 0, -100)), (0.3, -1.2, (0, 0, -100)), (6.0, 2.5, (1.5, -2, 40))]
+    cases += [(float(a), float(b), tuple(rng.uniform(-50, 50, 3))) for a, b in rng.uniform(-7, 7, (200, 2))]
+    for rx, ry, tr in cases:
+        got, want = rt.camera_matrix(rx, ry, tr), oracle.ref_camera_matrix(rx, ry, tr)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rx, ry, tr)
+    # the out[1][0] = 0 slip of rotate3 (core/Affine.h:180) is part of the matrices the reference uploads
+    m = rt.camera_matrix(0.0, 0.7, (0, 0, 0))
+    assert m[0, 2] != 0 and abs(m[0, 0] - np.cos(np.float32(0.7))) < 1e-6
+
+
+def test_bmp_bytes_equal_the_reference_writer(rt, oracle, tmp_path):
+    """rt_write_bmp32 against cpu_raycast/bmp.c's printImage (compiled where it lies), byte for byte."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    rng = np.random.default_rng(3)
+    for (w, h) in ((1, 1), (7, 5), (64, 48), (360, 20)):
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        a, b = str(tmp_path / f"a_{w}x{h}.bmp"), str(tmp_path / f"b_{w}x{h}.bmp")
+        rt.write_bmp32(a, img)
+        oracle.ref_print_image(img, b)
+        assert open(a, "rb").read() == open(b, "rb").read(), (w, h)
