@@ -421,6 +421,21 @@ def main():
             other = {"bvh": "sah", "ms_per_step": round(sms, 4), "value": round(n_local / (sms * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
             scene_s.close()
 
+        # the drop-in call with HOST buffers (pageable memory both ways): PCIe-inclusive, reported beside `value`, never as it
+        host_call = None
+        if world == 1 and W and not sharded and workload != "mirror5" and full_out:
+            hits_h = np.zeros_like(rays_h)
+            for _ in range(2):
+                rt._check(rt.lib.ray_scene_intersection(rt._ptr(rays_h), n_local, scene._h, rt._ptr(hits_h)))
+            c0 = time.perf_counter()
+            for _ in range(5):
+                rt._check(rt.lib.ray_scene_intersection(rt._ptr(rays_h), n_local, scene._h, rt._ptr(hits_h)))
+            hms = (time.perf_counter() - c0) / 5 * 1e3
+            host_call = {"ms_per_call": round(hms, 3), "value": round(n_local / (hms * 1e-3) / 1e6, 1), "unit": "Mrays/s",
+                         "pcie_GBs": round(128 * n_local / (hms * 1e-3) / 1e9, 1),
+                         "what": "ray_scene_intersection(host rays, n, scene, host hits): 64 B up + 64 B down per ray over PCIe included"}
+            del hits_h
+
         step_no[0] = 0
         if not sharded:
             step()                      # leaves frame 0's hits in hits_d for the spot check below
@@ -476,7 +491,7 @@ def main():
                        else "image centre first",
                        "parallelism": f"{world} x one process per GPU, " + ("cost-balanced image squares + RCCL gather + device scatter"
                                                                             if sharded else "frame-parallel")},
-            "roofline": roofline, "cpu_baseline": cpu, "same_launch_on_sah_tree": other,
+            "roofline": roofline, "cpu_baseline": cpu, "same_launch_on_sah_tree": other, "host_pointer_call": host_call,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)

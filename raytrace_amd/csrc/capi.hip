@@ -7,6 +7,8 @@
 #include <mutex>
 #include <new>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -155,6 +157,11 @@ struct rt_scene {
   // staging for host-pointer calls
   mutable void *d_stage_in = nullptr, *d_stage_out = nullptr;
   mutable size_t stage_in_bytes = 0, stage_out_bytes = 0;
+  // host-pointer calls move rays and hits in chunks through these pinned buffers (two per direction) on streams
+  // of their own, so the upload of chunk k+1, the trace of chunk k and the download of chunk k-1 overlap
+  mutable void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
+  mutable hipStream_t st_h2d = nullptr, st_trace = nullptr, st_d2h = nullptr;
+  mutable hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_trace[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -257,10 +264,12 @@ void SetShape(const rt_scene *s, rt::KernelArgs &a, int mode)
   }
 }
 
-int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStream_t stream)
+// `plain` launches use no dispatch-order table and leave the feedback state alone (the chunked host-pointer path:
+// its launches change shape from chunk to chunk, which would rebuild the tables every time).
+int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStream_t stream, bool plain = false)
 {
   SetShape(s, a, mode);
-  if (a.img_w && s->centre_first) {
+  if (a.img_w && s->centre_first && !plain) {
     int rc = EnsureOrder(s, a.img_w, a.img_h);
     if (rc != RT_OK) return rc;
     a.order = s->d_order;
@@ -282,7 +291,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     RT_HIP(hipMemsetAsync(a.cursor, 0, sizeof(uint32_t), stream));
   }
   int fb_slot = -1;
-  if (s->feedback == 1 && !count && a.n < kFeedbackMaxRays) {
+  if (s->feedback == 1 && !count && !plain && a.n < kFeedbackMaxRays) {
     if (s->fb_ntasks != a.ntasks || s->fb_n != a.n || s->fb_img_w != a.img_w) {  // new shape: start over
       int rc = ResetFeedback(s);
       if (rc != RT_OK) return rc;
@@ -313,7 +322,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     a.cost_radius = static_cast<uint32_t>(s->feedback_radius);
     a.cost_share = static_cast<uint32_t>(s->feedback_share);
   }
-  if (s->feedback == 1 && count && s->fb_launch >= 1u && s->fb_ntasks == a.ntasks && s->fb_n == a.n && s->fb_img_w == a.img_w) {
+  if (s->feedback == 1 && count && !plain && s->fb_launch >= 1u && s->fb_ntasks == a.ntasks && s->fb_n == a.n && s->fb_img_w == a.img_w) {
     // instrumented launch: follow the newest cost-sorted order, read-only
     const int newest = static_cast<int>((s->fb_launch - 1u) & 1u);
     RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[newest], 0));
@@ -591,6 +600,12 @@ void rt_scene_destroy(rt_scene *s)
     for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(s->ev_main[k]); (void)hipEventDestroy(s->ev_sort[k]); }
   }
   (void)hipFree(s->d_stage_in); (void)hipFree(s->d_stage_out);
+  for (int k = 0; k < 2; ++k) {
+    if (s->pin_in[k]) (void)hipHostFree(s->pin_in[k]);
+    if (s->pin_out[k]) (void)hipHostFree(s->pin_out[k]);
+    if (s->ev_h2d[k]) { (void)hipEventDestroy(s->ev_h2d[k]); (void)hipEventDestroy(s->ev_trace[k]); (void)hipEventDestroy(s->ev_d2h[k]); }
+  }
+  if (s->st_h2d) { (void)hipStreamDestroy(s->st_h2d); (void)hipStreamDestroy(s->st_trace); (void)hipStreamDestroy(s->st_d2h); }
   delete s;
 }
 
@@ -759,6 +774,77 @@ int rt_trace_primary(const rt_scene *s, int width, int height, const float origi
   return Enqueue(s, a, rt::kModePrimary, false, static_cast<hipStream_t>(stream));
 }
 
+// Host-pointer form: rays and/or hits live in ordinary (pageable) host memory.  Measured on the MI355X host
+// (tools/ubench/host_xfer.cpp, one 1080p table = 132.7 MB): hipMemcpy from pageable memory 4.8 ms up / 7.8 ms down,
+// from pinned memory 2.3 ms each way, one core's memcpy into pinned memory 4.4 ms.  So the records go through
+// pinned staging in chunks: the calling thread copies chunk k+1 into a pinned buffer while the DMA engines upload
+// chunk k and download chunk k-1 and the kernel traces in between, and a second thread copies finished chunks out
+// to the caller's buffer.  Pinning the caller's buffer in place was refused by the runtime for malloc'd memory.
+namespace {
+
+constexpr size_t kHostChunkRays = size_t(1) << 18;   // 16 MiB of records per direction per chunk
+
+// A thread that copies the upper half of a block while its owner copies the lower half: one core moves ~30 GB/s into
+// or out of pinned memory, two keep up with the 57 GB/s the DMA engines sustain.  Lives for one call.
+class CopyMate {
+ public:
+  CopyMate() : thread_([this] { Run(); }) {}
+  ~CopyMate()
+  {
+    quit_.store(true, std::memory_order_release);
+    thread_.join();
+  }
+  void Copy(void *dst, const void *src, size_t bytes)
+  {
+    const size_t half = (bytes / 2) & ~size_t(63);
+    dst_ = static_cast<char *>(dst) + half;
+    src_ = static_cast<const char *>(src) + half;
+    bytes_ = bytes - half;
+    posted_.store(posted_.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+    std::memcpy(dst, src, half);
+    while (done_.load(std::memory_order_acquire) != posted_.load(std::memory_order_relaxed)) std::this_thread::yield();
+  }
+
+ private:
+  void Run()
+  {
+    size_t seen = 0;
+    for (;;) {
+      while (posted_.load(std::memory_order_acquire) == seen) {
+        if (quit_.load(std::memory_order_acquire)) return;
+        std::this_thread::yield();
+      }
+      ++seen;
+      std::memcpy(dst_, src_, bytes_);
+      done_.store(seen, std::memory_order_release);
+    }
+  }
+  char *dst_ = nullptr;
+  const char *src_ = nullptr;
+  size_t bytes_ = 0;
+  std::atomic<size_t> posted_{0}, done_{0};
+  std::atomic<bool> quit_{false};
+  std::thread thread_;
+};
+
+int EnsureHostPipeline(const rt_scene *s)
+{
+  if (s->st_h2d) return RT_OK;
+  for (int k = 0; k < 2; ++k) {
+    RT_HIP(hipHostMalloc(&s->pin_in[k], kHostChunkRays * sizeof(rt_ray_isect), hipHostMallocDefault));
+    RT_HIP(hipHostMalloc(&s->pin_out[k], kHostChunkRays * sizeof(rt_ray_isect), hipHostMallocDefault));
+    RT_HIP(hipEventCreateWithFlags(&s->ev_h2d[k], hipEventDisableTiming));
+    RT_HIP(hipEventCreateWithFlags(&s->ev_trace[k], hipEventDisableTiming));
+    RT_HIP(hipEventCreateWithFlags(&s->ev_d2h[k], hipEventDisableTiming));
+  }
+  RT_HIP(hipStreamCreateWithFlags(&s->st_trace, hipStreamNonBlocking));
+  RT_HIP(hipStreamCreateWithFlags(&s->st_d2h, hipStreamNonBlocking));
+  RT_HIP(hipStreamCreateWithFlags(&s->st_h2d, hipStreamNonBlocking));   // last: its presence marks the set complete
+  return RT_OK;
+}
+
+}  // namespace
+
 int ray_scene_intersection(const void *rays, size_t n, const rt_scene *scene, void *hits)
 {
   if (!scene) return Fail(RT_ERR_INVALID, "null scene");
@@ -770,23 +856,102 @@ int ray_scene_intersection(const void *rays, size_t n, const rt_scene *scene, vo
   if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
   const size_t bytes = n * sizeof(rt_ray_isect);
   const bool in_dev = IsDevicePointer(rays), out_dev = IsDevicePointer(hits);
-  const void *d_in = rays;
-  void *d_out = hits;
-  if (!in_dev) {
-    int rc = EnsureStage(&scene->d_stage_in, &scene->stage_in_bytes, bytes);
+  if (in_dev && out_dev) {
+    int rc = rt_intersect_async(scene, rays, n, hits, nullptr, nullptr);
     if (rc != RT_OK) return rc;
-    RT_HIP(hipMemcpy(scene->d_stage_in, rays, bytes, hipMemcpyHostToDevice));
-    d_in = scene->d_stage_in;
+    RT_HIP(hipStreamSynchronize(nullptr));
+    return RT_OK;
+  }
+  const rt_scene *s = scene;
+  int rc = EnsureHostPipeline(s);
+  if (rc != RT_OK) return rc;
+  const rt_ray_isect *d_in = static_cast<const rt_ray_isect *>(rays);
+  rt_ray_isect *d_out = static_cast<rt_ray_isect *>(hits);
+  if (!in_dev) {
+    rc = EnsureStage(&s->d_stage_in, &s->stage_in_bytes, bytes);
+    if (rc != RT_OK) return rc;
+    d_in = static_cast<const rt_ray_isect *>(s->d_stage_in);
   }
   if (!out_dev) {
-    int rc = EnsureStage(&scene->d_stage_out, &scene->stage_out_bytes, bytes);
+    rc = EnsureStage(&s->d_stage_out, &s->stage_out_bytes, bytes);
     if (rc != RT_OK) return rc;
-    d_out = scene->d_stage_out;
+    d_out = static_cast<rt_ray_isect *>(s->d_stage_out);
   }
-  int rc = rt_intersect_async(scene, d_in, n, d_out, nullptr, nullptr);
-  if (rc != RT_OK) return rc;
-  RT_HIP(hipStreamSynchronize(nullptr));
-  if (!out_dev) RT_HIP(hipMemcpy(hits, d_out, bytes, hipMemcpyDeviceToHost));
+  // whole image rows per chunk when the rays are declared an image, so that every chunk is still walked in 8x8 tiles
+  size_t chunk = kHostChunkRays;
+  if (s->image_width > 0 && n % static_cast<size_t>(s->image_width) == 0 && static_cast<size_t>(s->image_width) * 8u <= kHostChunkRays)
+    chunk = kHostChunkRays / (static_cast<size_t>(s->image_width) * 8u) * (static_cast<size_t>(s->image_width) * 8u);
+  const size_t nchunks = (n + chunk - 1) / chunk;
+
+  // The copy-out thread: waits for chunk c's download, copies it to the caller, frees the pinned slot.
+  std::atomic<size_t> enqueued{0}, copied_out{0};
+  std::atomic<bool> failed{false};
+  std::thread out_thread;
+  if (!out_dev)
+    out_thread = std::thread([&] {
+      (void)hipSetDevice(s->device);
+      CopyMate mate;
+      for (size_t c = 0; c < nchunks; ++c) {
+        while (enqueued.load(std::memory_order_acquire) <= c) {
+          if (failed.load(std::memory_order_acquire)) return;
+          std::this_thread::yield();
+        }
+        const size_t off = c * chunk, cnt = std::min(chunk, n - off);
+        if (hipEventSynchronize(s->ev_d2h[c & 1]) != hipSuccess) { failed.store(true, std::memory_order_release); return; }
+        mate.Copy(static_cast<rt_ray_isect *>(hits) + off, s->pin_out[c & 1], cnt * sizeof(rt_ray_isect));
+        copied_out.store(c + 1, std::memory_order_release);
+      }
+    });
+  auto finish = [&](int code) {
+    if (code != RT_OK) failed.store(true, std::memory_order_release);
+    if (out_thread.joinable()) out_thread.join();
+    return code;
+  };
+#define RT_PIPE(call)                                             \
+  do {                                                            \
+    hipError_t e_ = (call);                                       \
+    if (e_ != hipSuccess) return finish(FailHip(e_, #call));      \
+  } while (0)
+
+  CopyMate in_mate;
+  for (size_t c = 0; c < nchunks; ++c) {
+    const int slot = static_cast<int>(c & 1);
+    const size_t off = c * chunk, cnt = std::min(chunk, n - off), cbytes = cnt * sizeof(rt_ray_isect);
+    if (!in_dev) {
+      if (c >= 2) RT_PIPE(hipEventSynchronize(s->ev_h2d[slot]));   // the upload that last used this pinned slot is done
+      in_mate.Copy(s->pin_in[slot], static_cast<const rt_ray_isect *>(rays) + off, cbytes);
+      RT_PIPE(hipMemcpyAsync(const_cast<rt_ray_isect *>(d_in) + off, s->pin_in[slot], cbytes, hipMemcpyHostToDevice, s->st_h2d));
+      RT_PIPE(hipEventRecord(s->ev_h2d[slot], s->st_h2d));
+      RT_PIPE(hipStreamWaitEvent(s->st_trace, s->ev_h2d[slot], 0));
+    }
+    {
+      rt::KernelArgs a;
+      FillArgs(s, a);
+      a.rays = d_in + off;
+      a.hits = d_out + off;
+      a.n = static_cast<uint32_t>(cnt);
+      rc = Enqueue(s, a, rt::kModeIntersect, false, s->st_trace, true);
+      if (rc != RT_OK) return finish(rc);
+    }
+    if (!out_dev) {
+      RT_PIPE(hipEventRecord(s->ev_trace[slot], s->st_trace));
+      // the pinned output slot is free once the copy-out thread has drained chunk c-2
+      while (c >= 2 && copied_out.load(std::memory_order_acquire) < c - 1) {
+        if (failed.load(std::memory_order_acquire)) return finish(Fail(RT_ERR_DEVICE, "download of a chunk failed"));
+        std::this_thread::yield();
+      }
+      RT_PIPE(hipStreamWaitEvent(s->st_d2h, s->ev_trace[slot], 0));
+      RT_PIPE(hipMemcpyAsync(s->pin_out[slot], d_out + off, cbytes, hipMemcpyDeviceToHost, s->st_d2h));
+      RT_PIPE(hipEventRecord(s->ev_d2h[slot], s->st_d2h));
+      enqueued.store(c + 1, std::memory_order_release);
+    }
+  }
+#undef RT_PIPE
+  if (out_thread.joinable()) out_thread.join();
+  if (failed.load()) return Fail(RT_ERR_DEVICE, "download of a chunk failed");
+  hipError_t e = hipStreamSynchronize(s->st_trace);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->st_h2d);
+  if (e != hipSuccess) return FailHip(e, "host-pointer pipeline");
   return RT_OK;
 }
 

@@ -71,10 +71,20 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
   std::vector<Item> todo{{0u, 1}};
   seen[0] = 1;
   int max_depth = 0;
+  std::vector<uint32_t> path;   // path[d - 1] = the node at depth d on the way to the node being visited
+  // A triangle outside the box of its leaf or of any ancestor would be culled for some rays (and, outside the root
+  // box, clamped off the quantization grid): the traversal's promise that the tree never changes a result needs
+  // every box on the path to hold it.  Same tolerance as the reference's own check (core/GeomUtil.cpp:94-101).
+  auto holds = [](rt_aabb const &b, rt_vec3 const &p) {
+    const float e = 0.000001f;
+    return p.x >= b.a.x - e && p.x <= b.b.x + e && p.y >= b.a.y - e && p.y <= b.b.y + e && p.z >= b.a.z - e && p.z <= b.b.z + e;
+  };
   while (!todo.empty()) {
     Item it = todo.back();
     todo.pop_back();
     rt_bvh_node const &n = nodes[it.node];
+    path.resize(static_cast<size_t>(it.depth));
+    path[it.depth - 1] = it.node;
     if (n.type == RT_BVH_INNER) {
       inner_id[it.node] = static_cast<uint32_t>(order.size());
       order.push_back(it.node);
@@ -96,6 +106,9 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
         rt_face const &f = faces[t];
         if (f.s[0] >= nverts || f.s[1] >= nverts || f.s[2] >= nverts) return "face vertex index out of range";
         rt_vec3 const &a = verts[f.s[0]], &b = verts[f.s[1]], &c = verts[f.s[2]];
+        for (uint32_t anc : path)
+          if (!holds(nodes[anc].aabb, a) || !holds(nodes[anc].aabb, b) || !holds(nodes[anc].aabb, c))
+            return "box of node " + std::to_string(anc) + " does not contain triangle " + std::to_string(t) + " of the leaf below it";
         GpuTri g;
         g.ax = a.x; g.ay = a.y; g.az = a.z; g.id = t;
         g.e1x = b.x - a.x; g.e1y = b.y - a.y; g.e1z = b.z - a.z; g.pad0 = 0;

@@ -89,6 +89,15 @@ def test_flatten_rejects_malformed_trees(rt):
     bad = good.copy(); bad[leaf, 16] = 7
     expect(bad, "unknown node type")
     expect(good[:2], "root with two children")
+    # boxes that do not hold their triangles: a shrunken leaf box, a shrunken inner box, a root box that is too small
+    fview = lambda a: a.view(np.float32)
+    bad = good.copy(); fview(bad)[leaf, 12:15] = fview(bad)[leaf, 8:11]            # leaf box max := min
+    expect(bad, "does not contain triangle")
+    inner = int(np.flatnonzero(good[:, 16] == 0)[1])
+    bad = good.copy(); fview(bad)[inner, 12:15] = fview(bad)[inner, 8:11]
+    expect(bad, f"box of node {inner} does not contain")
+    bad = good.copy(); fview(bad)[0, 8] = fview(bad)[0, 8] + 0.25 * (fview(bad)[0, 12] - fview(bad)[0, 8])
+    expect(bad, "box of node 0 does not contain")
     m2 = rt.Mesh.from_arrays(mesh.verts[:10], mesh.faces)
     expect_nodes = good
     with pytest.raises(rt.RtError, match="vertex index out of range"):

@@ -121,6 +121,54 @@ def test_incoherent_rays_match_oracle(rt, oracle, gpu):
         scene.close()
 
 
+def test_incoherent_rays_at_the_full_64_mi(rt, oracle, gpu):
+    """The divergence-stress configuration at its stated size: 64 Mi seeded AO-style rays through bunny_big in one
+    call (4.3 GB of ray records resident in HBM, 1 GB of compact hits).  Checked through what does not need the
+    oracle on every ray -- ids in range, a plausible hit share, the same bits from a second launch and from the
+    two-wide layout on a 4 Mi slice -- and against the brute-force oracle on a sub-sample spread over the whole set."""
+    import torch
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny_big.obj"), "tolerant")
+    bvh = rt.BVH(mesh, "fixed")
+    n, piece = 64 << 20, 4 << 20
+    rays_d = torch.empty((n, 16), dtype=torch.float32, device="cuda")
+    step = 16411                                     # sub-sample stride (prime), 4089 rays
+    sample = []
+    for off in range(0, n, piece):                   # generated and uploaded in slices: no 4.3 GB host table
+        part = rt.ao_rays(mesh, bvh.root_box, 1234, off, piece)
+        first = (-off) % step
+        sample.append(part[first::step].copy())
+        rays_d[off:off + piece].copy_(torch.from_numpy(part))
+    sample = np.concatenate(sample)
+    scene = rt.Scene(mesh, bvh, device=gpu, width=4)
+    try:
+        hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        scene.intersect_async(rays_d.data_ptr(), n, None, hits.data_ptr())
+        torch.cuda.synchronize()
+        ids = hits[:, 0].view(torch.int32)
+        hit = ids != -1
+        assert bool(((ids >= 0) & (ids < len(mesh.faces)) | ~hit).all())
+        share = float(hit.float().mean())
+        assert 0.02 < share < 0.5, share
+        again = torch.empty_like(hits)
+        scene.intersect_async(rays_d.data_ptr(), n, None, again.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(again.view(torch.int32), hits.view(torch.int32))
+        scene.set_param("width", 2)
+        scene.intersect_async(rays_d.data_ptr(), piece, None, again.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(again[:piece].view(torch.int32), hits[:piece].view(torch.int32))
+        got = hits[0::step].cpu().numpy()
+        assert len(got) == len(sample)
+        oid, ot, ou, ov = oracle.closest_hit(mesh.verts, mesh.faces, sample)
+        assert np.array_equal(got[:, 0].view(np.uint32), oid)
+        h = oid != rt.MISS_ID
+        assert h.sum() > 100
+        for k, want in ((1, ot), (2, ou), (3, ov)):
+            assert np.array_equal(bits(got[h, k]), bits(want[h]))
+    finally:
+        scene.close()
+
+
 def test_full_size_properties(rt, gpu):
     """Full benchmark sizes, checked through size-independent properties: the record layouts and both
     ray-to-lane mappings agree on every one of the 2 073 600 / 8 294 400 rays, hit records are
