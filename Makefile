@@ -15,7 +15,7 @@ HIPFLAGS = -std=c++17 -O3 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fhip-f
            -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -Wall -Wno-unused-parameter -Iinclude $(EXTRA_HIPFLAGS)
 
 HOST_SRCS = obj_loader centroid_bvh sah_bvh raygen flatten framebuffer
-HIP_SRCS = trace_kernels capi
+HIP_SRCS = trace_kernels flatten_device capi
 HOST_OBJS = $(foreach s,$(HOST_SRCS),$(BUILD)/$(s).o)
 HIP_OBJS = $(foreach s,$(HIP_SRCS),$(BUILD)/$(s).o)
 HDRS = $(wildcard $(CS)/*.h) $(wildcard include/*.h)

@@ -105,6 +105,8 @@ int rt_ao_rays(const rt_mesh *m, const rt_aabb *root, uint64_t seed, size_t firs
                                every tracing entry point fails with RT_ERR_DEVICE */
 #define RT_SCENE_WIDE2 0u   /* traverse the 64-byte two-child records  */
 #define RT_SCENE_WIDE4 4u   /* traverse the 128-byte four-child records */
+#define RT_SCENE_FLATTEN_DEVICE 0x100u /* OR-ed in: build the traversal records from the uploaded 80-byte nodes with GPU kernels
+                                          (the host then only validates and numbers the tree); the records are bit-identical */
 typedef struct rt_scene rt_scene;
 int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, size_t ntris,
                     const rt_float4 *normals, size_t nnormals, const rt_material *materials, size_t nmats,
@@ -114,6 +116,10 @@ void rt_scene_destroy(rt_scene *s);
  *               bytes per bvh2 node, bytes per bvh4 node, bytes per triangle record}
  * (node sizes are those of the layout currently selected by "quantized") */
 int rt_scene_info(const rt_scene *s, uint64_t info[8]);
+/* The re-flattened records as the scene holds them (host copies): which = 0 two-wide float records (64 B), 1 two-wide
+ * quantized (2 x 16 B per node), 2 four-wide float (128 B), 3 four-wide quantized (4 x 16 B), 4 triangle records
+ * (48 B, leaf order).  out == NULL only returns the size in *bytes.  For inspection and tests. */
+int rt_scene_records(const rt_scene *s, int which, void *out, size_t capacity, size_t *bytes);
 /* Tuning knobs (none of them changes a result, only the schedule or the record layout walked):
  *   "width"          2 or 4: which record layout the traversal walks.
  *   "quantized"      1: records hold 16-bit grid-quantized boxes, 16 bytes per child; 0: float boxes, 32 bytes

@@ -88,6 +88,7 @@ def _load():
         "rt_scene_create": (i32, [vp, sz, vp, sz, vp, sz, vp, sz, vp, sz, i32, u32, C.POINTER(vp)]),
         "rt_scene_destroy": (None, [vp]),
         "rt_scene_info": (i32, [vp, C.POINTER(u64)]),
+        "rt_scene_records": (i32, [vp, i32, vp, sz, C.POINTER(sz)]),
         "rt_scene_set_param": (i32, [vp, C.c_char_p, i32]),
         "ray_scene_intersection": (i32, [vp, sz, vp, vp]),
         "rt_intersect_async": (i32, [vp, vp, sz, vp, vp, vp]),
@@ -243,13 +244,14 @@ class Scene:
     """Device-resident scene.  Stands in for the buffer uploads and static kernel-argument
     bindings of render_client/img_main.cpp:243-249,293,298-311."""
 
-    def __init__(self, mesh, bvh, device=0, width=2):
+    def __init__(self, mesh, bvh, device=0, width=2, flatten_on_device=False):
         h = C.c_void_p()
         nodes = np.ascontiguousarray(bvh.nodes if isinstance(bvh, BVH) else bvh, dtype=np.uint32).reshape(-1, 20)
         _check(lib.rt_scene_create(_ptr(mesh.verts), len(mesh.verts), _ptr(mesh.faces), len(mesh.faces),
                                    _ptr(mesh.normals) if len(mesh.normals) else None, len(mesh.normals),
                                    _ptr(mesh.materials) if len(mesh.materials) else None, len(mesh.materials),
-                                   _ptr(nodes), len(nodes), device, 4 if width == 4 else 0, C.byref(h)))
+                                   _ptr(nodes), len(nodes), device, (4 if width == 4 else 0) | (0x100 if flatten_on_device else 0),
+                                   C.byref(h)))
         self._h = h
         self.device = device
 
@@ -258,6 +260,14 @@ class Scene:
         _check(lib.rt_scene_info(self._h, v))
         keys = ["nodes2", "nodes4", "leaf_tris", "depth2", "depth4", "node2_bytes", "node4_bytes", "tri_bytes"]
         return dict(zip(keys, [int(x) for x in v]))
+
+    def records(self, which):
+        """Raw bytes (u8 array) of one re-flattened record array: 0 nodes2, 1 nodesq2, 2 nodes4, 3 nodesq4, 4 triangles."""
+        n = C.c_size_t()
+        _check(lib.rt_scene_records(self._h, which, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.uint8)
+        _check(lib.rt_scene_records(self._h, which, _ptr(out), len(out), C.byref(n)))
+        return out
 
     def set_param(self, key, value):
         _check(lib.rt_scene_set_param(self._h, key.encode(), int(value)))

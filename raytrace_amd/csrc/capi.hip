@@ -16,6 +16,7 @@
 #include "../../include/rt_amd.h"
 #include "device_scene.h"
 #include "host_scene.h"
+#include "flatten_device.h"
 
 namespace {
 
@@ -528,7 +529,10 @@ int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, s
 {
   if (!out || !verts || !faces || !bvh_nodes) return Fail(RT_ERR_INVALID, "null argument");
   if ((!normals && nnormals) || (!materials && nmats)) return Fail(RT_ERR_INVALID, "null argument");
+  const bool on_device = (flags & RT_SCENE_FLATTEN_DEVICE) != 0;
+  flags &= ~RT_SCENE_FLATTEN_DEVICE;
   if (flags != RT_SCENE_WIDE2 && flags != RT_SCENE_WIDE4) return Fail(RT_ERR_INVALID, "unknown scene flags");
+  if (on_device && device == RT_DEVICE_NONE) return Fail(RT_ERR_DEVICE, "RT_SCENE_FLATTEN_DEVICE needs a device");
   if (device != RT_DEVICE_NONE) {
     int ndev = 0;
     RT_HIP(hipGetDeviceCount(&ndev));
@@ -538,8 +542,11 @@ int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, s
   rt_scene *s = new (std::nothrow) rt_scene;
   if (!s) return Fail(RT_ERR_NOMEM, "out of memory");
   std::string why;
+  rt::FlatIndex ix;
   try {
-    why = rt::Flatten(bvh_nodes, nnodes, verts, nverts, faces, ntris, &s->flat);
+    // on the device: the host only validates and numbers; the records are built by flatten_device.hip further down
+    if (on_device) why = rt::FlattenIndexPass(bvh_nodes, nnodes, verts, nverts, faces, ntris, &ix);
+    else why = rt::Flatten(bvh_nodes, nnodes, verts, nverts, faces, ntris, &s->flat);
   } catch (const std::exception &ex) {
     why = ex.what();
   }
@@ -563,13 +570,42 @@ int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, s
     StaticState *st = nullptr;
     rc = StaticScratch(device, &st);
   }
-  if (rc == RT_OK) rc = Upload(&s->d_nodes2, s->flat.nodes2.data(), s->flat.nodes2.size() * sizeof(rt::GpuNode2));
-  if (rc == RT_OK) rc = Upload(&s->d_nodes4, s->flat.nodes4.data(), s->flat.nodes4.size() * sizeof(rt::GpuNode4));
-  if (rc == RT_OK) rc = Upload(&s->d_nodesq2, s->flat.nodesq2.data(), s->flat.nodesq2.size() * sizeof(rt::GpuChildQ));
-  if (rc == RT_OK) rc = Upload(&s->d_nodesq4, s->flat.nodesq4.data(), s->flat.nodesq4.size() * sizeof(rt::GpuChildQ));
-  if (rc == RT_OK) rc = Upload(&s->d_tris, s->flat.tris.data(), s->flat.tris.size() * sizeof(rt::GpuTri));
   if (rc == RT_OK) rc = Upload(&s->d_verts, verts, nverts * sizeof(rt_vec3));
   if (rc == RT_OK) rc = Upload(&s->d_faces, faces, ntris * sizeof(rt_face));
+  if (rc == RT_OK && !on_device) {
+    rc = Upload(&s->d_nodes2, s->flat.nodes2.data(), s->flat.nodes2.size() * sizeof(rt::GpuNode2));
+    if (rc == RT_OK) rc = Upload(&s->d_nodes4, s->flat.nodes4.data(), s->flat.nodes4.size() * sizeof(rt::GpuNode4));
+    if (rc == RT_OK) rc = Upload(&s->d_nodesq2, s->flat.nodesq2.data(), s->flat.nodesq2.size() * sizeof(rt::GpuChildQ));
+    if (rc == RT_OK) rc = Upload(&s->d_nodesq4, s->flat.nodesq4.data(), s->flat.nodesq4.size() * sizeof(rt::GpuChildQ));
+    if (rc == RT_OK) rc = Upload(&s->d_tris, s->flat.tris.data(), s->flat.tris.size() * sizeof(rt::GpuTri));
+  }
+  if (rc == RT_OK && on_device) {
+    // the caller's 80-byte nodes go up as they are; the kernels of flatten_device.hip turn them into the records
+    rt_bvh_node *d_caller_nodes = nullptr;
+    rc = Upload(&d_caller_nodes, bvh_nodes, nnodes * sizeof(rt_bvh_node));
+    rt::DeviceFlat df;
+    if (rc == RT_OK) {
+      hipError_t e = rt::FlattenOnDevice(ix, d_caller_nodes, nnodes, s->d_verts, s->d_faces, &df);
+      if (e != hipSuccess) rc = FailHip(e, "device flatten");
+    }
+    (void)hipFree(d_caller_nodes);
+    if (rc == RT_OK) {
+      s->d_nodes2 = reinterpret_cast<float4 *>(df.nodes2); s->d_nodesq2 = reinterpret_cast<float4 *>(df.nodesq2);
+      s->d_nodes4 = reinterpret_cast<float4 *>(df.nodes4); s->d_nodesq4 = reinterpret_cast<float4 *>(df.nodesq4);
+      s->d_tris = reinterpret_cast<float4 *>(df.tris);
+      // host copies of the device-built records: the fetch counter, the wave model and rt_scene_records read them
+      s->flat.nodes2.resize(df.n2); s->flat.nodesq2.resize(df.n2 * 2);
+      s->flat.nodes4.resize(df.n4); s->flat.nodesq4.resize(df.n4 * 4);
+      s->flat.tris.resize(df.ntris);
+      hipError_t e = hipMemcpy(s->flat.nodes2.data(), df.nodes2, df.n2 * sizeof(rt::GpuNode2), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(s->flat.nodesq2.data(), df.nodesq2, df.n2 * 2 * sizeof(rt::GpuChildQ), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(s->flat.nodes4.data(), df.nodes4, df.n4 * sizeof(rt::GpuNode4), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(s->flat.nodesq4.data(), df.nodesq4, df.n4 * 4 * sizeof(rt::GpuChildQ), hipMemcpyDeviceToHost);
+      if (e == hipSuccess && df.ntris) e = hipMemcpy(s->flat.tris.data(), df.tris, df.ntris * sizeof(rt::GpuTri), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) rc = FailHip(e, "device flatten read-back");
+      rt::FlattenFinish(bvh_nodes, ix, df.depth4, &s->flat);
+    }
+  }
   if (rc == RT_OK) rc = Upload(&s->d_normals, normals, nnormals * sizeof(rt_float4));
   if (rc == RT_OK) rc = Upload(&s->d_mats, materials, nmats * sizeof(rt_material));
   if (rc == RT_OK) rc = Upload(&s->d_stats, nullptr, kStatShards * 16 * sizeof(unsigned long long));
@@ -617,6 +653,26 @@ int rt_scene_info(const rt_scene *s, uint64_t info[8])
   info[5] = s->quant ? 2 * sizeof(rt::GpuChildQ) : sizeof(rt::GpuNode2);
   info[6] = s->quant ? 4 * sizeof(rt::GpuChildQ) : sizeof(rt::GpuNode4);
   info[7] = sizeof(rt::GpuTri);
+  return RT_OK;
+}
+
+int rt_scene_records(const rt_scene *s, int which, void *out, size_t capacity, size_t *bytes)
+{
+  if (!s || !bytes) return Fail(RT_ERR_INVALID, "null argument");
+  const void *src = nullptr;
+  size_t n = 0;
+  switch (which) {
+    case 0: src = s->flat.nodes2.data(); n = s->flat.nodes2.size() * sizeof(rt::GpuNode2); break;
+    case 1: src = s->flat.nodesq2.data(); n = s->flat.nodesq2.size() * sizeof(rt::GpuChildQ); break;
+    case 2: src = s->flat.nodes4.data(); n = s->flat.nodes4.size() * sizeof(rt::GpuNode4); break;
+    case 3: src = s->flat.nodesq4.data(); n = s->flat.nodesq4.size() * sizeof(rt::GpuChildQ); break;
+    case 4: src = s->flat.tris.data(); n = s->flat.tris.size() * sizeof(rt::GpuTri); break;
+    default: return Fail(RT_ERR_INVALID, "unknown record array");
+  }
+  *bytes = n;
+  if (!out) return RT_OK;
+  if (capacity < n) return Fail(RT_ERR_INVALID, "record buffer too small");
+  if (n) std::memcpy(out, src, n);
   return RT_OK;
 }
 

@@ -11,6 +11,7 @@
 // dependent 16-byte vertex fetches per triangle, tracekernel.ck:159-162).
 #include "host_scene.h"
 #include "trace_math.h"
+#include "flatten_math.h"
 
 #include <algorithm>
 #include <array>
@@ -19,54 +20,20 @@
 
 namespace rt {
 
-namespace {
-
-// Grid index of the plane at or below (down) / at or above (up) coordinate v, with one cell of slack.
-inline uint32_t QuantDown(float v, float lo, float step)
+// Validation and numbering: one sequential walk of the caller's tree.  Everything after it (records, quantization,
+// the four-wide collapse) is per-node work that the host (Flatten) or the device (FlattenOnDevice) can do.
+std::string FlattenIndexPass(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *verts, size_t nverts,
+                             rt_face const *faces, size_t ntris, FlatIndex *ix)
 {
-  double q = std::floor((static_cast<double>(v) - lo) / step);
-  while (q > 0 && lo + q * static_cast<double>(step) > v) q -= 1;
-  q -= 2;  // one cell for the grid arithmetic, one for the traversal's biased plane constant
-  return static_cast<uint32_t>(std::min(65535.0, std::max(0.0, q)));
-}
-inline uint32_t QuantUp(float v, float lo, float step)
-{
-  double q = std::ceil((static_cast<double>(v) - lo) / step);
-  while (q < 65535 && lo + q * static_cast<double>(step) < v) q += 1;
-  q += 2;
-  return static_cast<uint32_t>(std::min(65535.0, std::max(0.0, q)));
-}
-
-inline GpuChildQ QuantChild(rt_aabb const &b, uint32_t ref, const float *lo, const float *step)
-{
-  GpuChildQ c;
-  c.x = QuantDown(b.a.x, lo[0], step[0]) | (QuantUp(b.b.x, lo[0], step[0]) << 16);
-  c.y = QuantDown(b.a.y, lo[1], step[1]) | (QuantUp(b.b.y, lo[1], step[1]) << 16);
-  c.z = QuantDown(b.a.z, lo[2], step[2]) | (QuantUp(b.b.z, lo[2], step[2]) << 16);
-  c.ref = ref;
-  return c;
-}
-
-inline float Area(rt_aabb const &b)
-{
-  float x = b.b.x - b.a.x, y = b.b.y - b.a.y, z = b.b.z - b.a.z;
-  return x * y + y * z + z * x;
-}
-
-}  // namespace
-
-std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *verts, size_t nverts,
-                    rt_face const *faces, size_t ntris, FlatScene *out)
-{
-  *out = FlatScene();
+  *ix = FlatIndex();
   if (!nodes || nnodes < 3) return "bvh needs a root with two children";
   if (nodes[0].type != RT_BVH_INNER) return "bvh root must be an inner node";
   if (ntris >= (1u << 28)) return "too many triangles for the 28-bit leaf reference";
 
   // ---- validate + number inner nodes and triangles in depth-first pre-order -------
-  std::vector<uint32_t> inner_id(nnodes, 0xFFFFFFFFu), leaf_ref(nnodes, 0);
+  ix->inner_id.assign(nnodes, 0xFFFFFFFFu);
+  ix->leaf_ref.assign(nnodes, 0);
   std::vector<uint8_t> seen(nnodes, 0);
-  std::vector<uint32_t> order;  // reference indices of inner nodes, in new order
   struct Item { uint32_t node; int depth; };
   std::vector<Item> todo{{0u, 1}};
   seen[0] = 1;
@@ -86,8 +53,8 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
     path.resize(static_cast<size_t>(it.depth));
     path[it.depth - 1] = it.node;
     if (n.type == RT_BVH_INNER) {
-      inner_id[it.node] = static_cast<uint32_t>(order.size());
-      order.push_back(it.node);
+      ix->inner_id[it.node] = static_cast<uint32_t>(ix->order.size());
+      ix->order.push_back(it.node);
       max_depth = std::max(max_depth, it.depth);
       for (int k = 1; k >= 0; --k) {  // child 0 is processed first
         uint32_t c = n.node.inner.children_index[k];
@@ -99,7 +66,7 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
     } else if (n.type == RT_BVH_LEAF) {
       uint32_t cnt = n.node.leaf.count;
       if (cnt > RT_TRIS_PER_LEAF) return "leaf holds more than 4 triangles";
-      uint32_t first = static_cast<uint32_t>(out->tris.size());
+      uint32_t first = static_cast<uint32_t>(ix->tri_of_record.size());
       for (uint32_t j = 0; j < cnt; ++j) {
         uint32_t t = n.node.leaf.tris[j];
         if (t >= ntris) return "leaf triangle index out of range";
@@ -109,195 +76,99 @@ std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *vert
         for (uint32_t anc : path)
           if (!holds(nodes[anc].aabb, a) || !holds(nodes[anc].aabb, b) || !holds(nodes[anc].aabb, c))
             return "box of node " + std::to_string(anc) + " does not contain triangle " + std::to_string(t) + " of the leaf below it";
-        GpuTri g;
-        g.ax = a.x; g.ay = a.y; g.az = a.z; g.id = t;
-        g.e1x = b.x - a.x; g.e1y = b.y - a.y; g.e1z = b.z - a.z; g.pad0 = 0;
-        g.e2x = c.x - a.x; g.e2y = c.y - a.y; g.e2z = c.z - a.z; g.pad1 = 0;
-        out->tris.push_back(g);
+        ix->tri_of_record.push_back(t);
       }
-      leaf_ref[it.node] = kLeafBit | (first << 3) | cnt;
+      ix->leaf_ref[it.node] = kLeafBit | (first << 3) | cnt;
     } else {
       return "unknown node type";
     }
   }
-
-  auto ref_of = [&](uint32_t node) { return nodes[node].type == RT_BVH_INNER ? inner_id[node] : leaf_ref[node]; };
+  ix->depth2 = max_depth;
 
   // ---- quantization grid over the root box (which spans every vertex) --------------------
-  {
-    const float lo[3] = {nodes[0].aabb.a.x, nodes[0].aabb.a.y, nodes[0].aabb.a.z};
-    const float hi[3] = {nodes[0].aabb.b.x, nodes[0].aabb.b.y, nodes[0].aabb.b.z};
-    for (int k = 0; k < 3; ++k) {
-      out->grid_lo[k] = lo[k];
-      float st = (hi[k] - lo[k]) / 65535.f;
-      if (!(st > 0.f)) st = 1e-6f;
-      // the top plane must reach the box: widen the step until lo + 65535*step >= hi in exact arithmetic
-      while (static_cast<double>(lo[k]) + 65535.0 * st < hi[k]) st = std::nextafter(st, 3.0e38f);
-      out->grid_step[k] = st;
-    }
+  const float lo[3] = {nodes[0].aabb.a.x, nodes[0].aabb.a.y, nodes[0].aabb.a.z};
+  const float hi[3] = {nodes[0].aabb.b.x, nodes[0].aabb.b.y, nodes[0].aabb.b.z};
+  for (int k = 0; k < 3; ++k) {
+    ix->grid_lo[k] = lo[k];
+    float st = (hi[k] - lo[k]) / 65535.f;
+    if (!(st > 0.f)) st = 1e-6f;
+    // the top plane must reach the box: widen the step until lo + 65535*step >= hi in exact arithmetic
+    while (static_cast<double>(lo[k]) + 65535.0 * st < hi[k]) st = std::nextafter(st, 3.0e38f);
+    ix->grid_step[k] = st;
   }
+  return std::string();
+}
 
-  // ---- BVH2 records ---------------------------------------------------------------
-  out->nodes2.resize(order.size());
-  out->nodesq2.resize(order.size() * 2);
-  for (size_t i = 0; i < order.size(); ++i) {
-    rt_bvh_node const &n = nodes[order[i]];
-    GpuNode2 g;
-    std::memset(&g, 0, sizeof g);
-    const uint32_t c0 = n.node.inner.children_index[0], c1 = n.node.inner.children_index[1];
-    rt_aabb const &b0 = nodes[c0].aabb, &b1 = nodes[c1].aabb;
-    g.lo0[0] = b0.a.x; g.lo0[1] = b0.a.y; g.lo0[2] = b0.a.z; g.hi0[0] = b0.b.x; g.hi0[1] = b0.b.y; g.hi0[2] = b0.b.z;
-    g.lo1[0] = b1.a.x; g.lo1[1] = b1.a.y; g.lo1[2] = b1.a.z; g.hi1[0] = b1.b.x; g.hi1[1] = b1.b.y; g.hi1[2] = b1.b.z;
-    g.child[0] = ref_of(c0);
-    g.child[1] = ref_of(c1);
-    out->nodes2[i] = g;
-    out->nodesq2[2 * i] = QuantChild(b0, g.child[0], out->grid_lo, out->grid_step);
-    out->nodesq2[2 * i + 1] = QuantChild(b1, g.child[1], out->grid_lo, out->grid_step);
-  }
-  out->depth2 = max_depth;
-  out->stack2 = max_depth + 1;
-
-  // ---- BVH4: pull grandchildren up, largest box first; then open leaves into the slots left over ----------
-  // Each BVH4 node is rooted at a BVH2 inner node; the set {child0, child1} is widened by replacing its largest
-  // inner member with that member's two children until it holds four entries or only leaves.  Slots still free
-  // after that (a quarter of all slots on the benchmark meshes) would be tested by every visiting ray for
-  // nothing, so they are given to the node's leaves: a leaf of 2..4 triangles is split into two runs with their
-  // own, tighter boxes (the two-way partition of its triangles with the least summed area x count; a leaf's
-  // records are reordered to make both runs contiguous).  Same triangles under the same node, same node count,
-  // fewer triangle tests per ray.
-  {
-    struct Kid {
-      bool inner;
-      uint32_t node;        // inner: reference-node index
-      uint32_t first, cnt;  // leaf: run of triangle records
-      rt_aabb box;
-    };
-    auto kid_of = [&](uint32_t node) {
-      Kid k{};
-      k.inner = nodes[node].type == RT_BVH_INNER;
-      k.node = node;
-      k.box = nodes[node].aabb;
-      if (!k.inner) { k.first = (leaf_ref[node] & ~kLeafBit) >> 3; k.cnt = leaf_ref[node] & 7u; }
-      return k;
-    };
-    auto tri_box = [&](uint32_t rec, rt_aabb *b, bool init) {
-      rt_face const &f = faces[out->tris[rec].id];
-      for (int c = 0; c < 3; ++c) {
-        rt_vec3 const &v = verts[f.s[c]];
-        if (init && c == 0) { b->a = v; b->b = v; continue; }
-        b->a.x = std::min(b->a.x, v.x); b->a.y = std::min(b->a.y, v.y); b->a.z = std::min(b->a.z, v.z);
-        b->b.x = std::max(b->b.x, v.x); b->b.y = std::max(b->b.y, v.y); b->b.z = std::max(b->b.z, v.z);
-      }
-    };
-    std::vector<uint32_t> id4(nnodes, 0xFFFFFFFFu);
-    std::vector<std::array<Kid, 4>> kids;
-    std::vector<int> nk;
-    id4[0] = 0;
-    std::vector<uint32_t> roots{0u};
-    std::vector<int> depths{1};
-    int max4 = 0;
-    for (size_t qi = 0; qi < roots.size(); ++qi) {  // breadth-first numbering keeps the top levels dense
-      const uint32_t r = roots[qi];
-      max4 = std::max(max4, depths[qi]);
-      std::array<Kid, 4> set{};
-      set[0] = kid_of(nodes[r].node.inner.children_index[0]);
-      set[1] = kid_of(nodes[r].node.inner.children_index[1]);
-      int n = 2;
-      while (n < 4) {
-        int pick = -1;
-        float best = -1.f;
-        for (int k = 0; k < n; ++k)
-          if (set[k].inner) {
-            float a = Area(set[k].box);
-            if (a > best) { best = a; pick = k; }
-          }
-        if (pick < 0) break;
-        const uint32_t p = set[pick].node;
-        set[pick] = kid_of(nodes[p].node.inner.children_index[0]);
-        set[n++] = kid_of(nodes[p].node.inner.children_index[1]);
-      }
-      while (n < 4) {
-        int pick = -1;
-        float best = -1.f;
-        for (int k = 0; k < n; ++k)
-          if (!set[k].inner && set[k].cnt >= 2) {
-            float a = Area(set[k].box) * static_cast<float>(set[k].cnt);
-            if (a > best) { best = a; pick = k; }
-          }
-        if (pick < 0) break;
-        const Kid leaf = set[pick];
-        // every two-way partition of the <= 4 records: bit j of `mask` set = record j goes to the second run
-        uint32_t best_mask = 0;
-        float best_cost = kFltMax;
-        for (uint32_t mask = 1; mask + 1 < (1u << leaf.cnt); ++mask) {
-          if (mask & 1u) continue;  // record 0 stays in the first run: each partition is seen once
-          rt_aabb ba{}, bb{};
-          uint32_t na = 0, nb = 0;
-          for (uint32_t j = 0; j < leaf.cnt; ++j) {
-            if (mask >> j & 1u) tri_box(leaf.first + j, &bb, nb++ == 0);
-            else tri_box(leaf.first + j, &ba, na++ == 0);
-          }
-          const float cost = Area(ba) * static_cast<float>(na) + Area(bb) * static_cast<float>(nb);
-          if (cost < best_cost) { best_cost = cost; best_mask = mask; }
-        }
-        GpuTri tmp[4];
-        uint32_t na = 0;
-        for (uint32_t j = 0; j < leaf.cnt; ++j)
-          if (!(best_mask >> j & 1u)) tmp[na++] = out->tris[leaf.first + j];
-        uint32_t w = na;
-        for (uint32_t j = 0; j < leaf.cnt; ++j)
-          if (best_mask >> j & 1u) tmp[w++] = out->tris[leaf.first + j];
-        for (uint32_t j = 0; j < leaf.cnt; ++j) out->tris[leaf.first + j] = tmp[j];
-        Kid a{}, b{};
-        a.inner = b.inner = false;
-        a.first = leaf.first; a.cnt = na;
-        b.first = leaf.first + na; b.cnt = leaf.cnt - na;
-        for (uint32_t j = 0; j < a.cnt; ++j) tri_box(a.first + j, &a.box, j == 0);
-        for (uint32_t j = 0; j < b.cnt; ++j) tri_box(b.first + j, &b.box, j == 0);
-        set[pick] = a;
-        set[n++] = b;
-      }
-      for (int k = 0; k < n; ++k)
-        if (set[k].inner) {
-          id4[set[k].node] = static_cast<uint32_t>(roots.size());
-          roots.push_back(set[k].node);
-          depths.push_back(depths[qi] + 1);
-        }
-      kids.push_back(set);
-      nk.push_back(n);
-    }
-    out->nodes4.resize(roots.size());
-    out->nodesq4.resize(roots.size() * 4);
-    for (size_t i = 0; i < roots.size(); ++i) {
-      GpuNode4 g;
-      std::memset(&g, 0, sizeof g);
-      for (int k = 0; k < 4; ++k) {
-        if (k < nk[i]) {
-          Kid const &kid = kids[i][k];
-          rt_aabb const &b = kid.box;
-          g.lox[k] = b.a.x; g.loy[k] = b.a.y; g.loz[k] = b.a.z;
-          g.hix[k] = b.b.x; g.hiy[k] = b.b.y; g.hiz[k] = b.b.z;
-          g.child[k] = kid.inner ? id4[kid.node] : (kLeafBit | (kid.first << 3) | kid.cnt);
-          out->nodesq4[4 * i + k] = QuantChild(b, g.child[k], out->grid_lo, out->grid_step);
-        } else {  // unused slot: inverted box never passes the slab test
-          g.lox[k] = g.loy[k] = g.loz[k] = kFltMax;
-          g.hix[k] = g.hiy[k] = g.hiz[k] = -kFltMax;
-          g.child[k] = kEmptyRef;
-          out->nodesq4[4 * i + k] = GpuChildQ{0x0000FFFFu, 0x0000FFFFu, 0x0000FFFFu, kEmptyRef};
-        }
-      }
-      out->nodes4[i] = g;
-    }
-    out->depth4 = max4;
-    out->stack4 = 3 * max4 + 1;
-  }
-
+// What does not depend on who builds the records.
+void FlattenFinish(rt_bvh_node const *nodes, FlatIndex const &ix, int depth4, FlatScene *out)
+{
+  for (int k = 0; k < 3; ++k) { out->grid_lo[k] = ix.grid_lo[k]; out->grid_step[k] = ix.grid_step[k]; }
+  out->depth2 = ix.depth2;
+  out->stack2 = ix.depth2 + 1;
+  out->depth4 = depth4;
+  out->stack4 = 3 * depth4 + 1;
   out->root_box = nodes[0].aabb;
   float s = 0.f;
   for (float v : {nodes[0].aabb.a.x, nodes[0].aabb.a.y, nodes[0].aabb.a.z, nodes[0].aabb.b.x, nodes[0].aabb.b.y,
                   nodes[0].aabb.b.z})
     s = std::max(s, std::fabs(v));
   out->scale = s;
+}
+
+std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *verts, size_t nverts,
+                    rt_face const *faces, size_t ntris, FlatScene *out)
+{
+  *out = FlatScene();
+  FlatIndex ix;
+  std::string why = FlattenIndexPass(nodes, nnodes, verts, nverts, faces, ntris, &ix);
+  if (!why.empty()) return why;
+
+  // ---- triangle records, leaf order ----------------------------------------------------
+  out->tris.resize(ix.tri_of_record.size());
+  for (size_t i = 0; i < out->tris.size(); ++i) out->tris[i] = MakeTri(faces, verts, ix.tri_of_record[i]);
+
+  auto ref_of = [&](uint32_t node) { return nodes[node].type == RT_BVH_INNER ? ix.inner_id[node] : ix.leaf_ref[node]; };
+
+  // ---- BVH2 records ---------------------------------------------------------------
+  out->nodes2.resize(ix.order.size());
+  out->nodesq2.resize(ix.order.size() * 2);
+  for (size_t i = 0; i < ix.order.size(); ++i) {
+    rt_bvh_node const &n = nodes[ix.order[i]];
+    MakeNode2(nodes, ix.order[i], ref_of(n.node.inner.children_index[0]), ref_of(n.node.inner.children_index[1]), ix.grid_lo,
+              ix.grid_step, &out->nodes2[i], &out->nodesq2[2 * i]);
+  }
+
+  // ---- BVH4: one four-wide node per chosen two-wide inner node, numbered breadth first (keeps the top levels
+  // dense); ChooseKids4 (flatten_math.h) picks each node's children ---------------------
+  std::vector<uint32_t> id4(nnodes, 0xFFFFFFFFu);
+  std::vector<std::array<Kid, 4>> kids;
+  std::vector<int> nk;
+  id4[0] = 0;
+  std::vector<uint32_t> roots{0u};
+  std::vector<int> depths{1};
+  int max4 = 0;
+  for (size_t qi = 0; qi < roots.size(); ++qi) {
+    max4 = std::max(max4, depths[qi]);
+    std::array<Kid, 4> set{};
+    const int n = ChooseKids4(nodes, ix.leaf_ref.data(), out->tris.data(), faces, verts, roots[qi], set.data());
+    for (int k = 0; k < n; ++k)
+      if (set[k].inner) {
+        id4[set[k].node] = static_cast<uint32_t>(roots.size());
+        roots.push_back(set[k].node);
+        depths.push_back(depths[qi] + 1);
+      }
+    kids.push_back(set);
+    nk.push_back(n);
+  }
+  out->nodes4.resize(roots.size());
+  out->nodesq4.resize(roots.size() * 4);
+  for (size_t i = 0; i < roots.size(); ++i) {
+    uint32_t child_ref[4] = {0, 0, 0, 0};
+    for (int k = 0; k < nk[i]; ++k)
+      child_ref[k] = kids[i][k].inner ? id4[kids[i][k].node] : (kLeafBit | (kids[i][k].first << 3) | kids[i][k].cnt);
+    MakeNode4(kids[i].data(), nk[i], child_ref, ix.grid_lo, ix.grid_step, &out->nodes4[i], &out->nodesq4[4 * i]);
+  }
+  FlattenFinish(nodes, ix, max4, out);
   return std::string();
 }
 

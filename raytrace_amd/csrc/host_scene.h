@@ -147,6 +147,19 @@ struct FlatScene {
   float scale = 0.f;    // max |coordinate| of the root box; feeds the per-ray slab padding
 };
 
+// Result of the sequential part of the re-flattening: the numbering of inner nodes and triangle records.
+struct FlatIndex {
+  std::vector<uint32_t> order;          // caller-array indices of the inner nodes, in the new (depth-first) order
+  std::vector<uint32_t> inner_id;       // per caller node: its two-wide record index (inner nodes)
+  std::vector<uint32_t> leaf_ref;       // per caller node: kLeafBit | first record << 3 | count (leaves)
+  std::vector<uint32_t> tri_of_record;  // per triangle record: original triangle index
+  int depth2 = 0;
+  float grid_lo[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
+};
+std::string FlattenIndexPass(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *verts, size_t nverts,
+                             rt_face const *faces, size_t ntris, FlatIndex *ix);
+void FlattenFinish(rt_bvh_node const *nodes, FlatIndex const &ix, int depth4, FlatScene *out);
+
 // Validates `nodes` (indices in range, tree-shaped, leaves <= 4 triangles, root inner) and builds both layouts.
 // Returns an empty string on success, else the reason.
 std::string Flatten(rt_bvh_node const *nodes, size_t nnodes, rt_vec3 const *verts, size_t nverts,
