@@ -193,7 +193,11 @@ int rt_trace_primary(const rt_scene *scene, int width, int height, const float o
  * direction (w=0); op 1 reflects direction about the record's normal and nudges the
  * origin by normal*1e-5.  Writes the output record and, if rgba is non-NULL, the RGBA32F
  * pixel |n.d|*material.color, alpha = material.Rf ((0,0,0,0) on a miss).  Device pointers,
- * enqueued on `stream`. */
+ * enqueued on `stream`.
+ * One deliberate difference from the reference in op 1: a record whose previous pass missed (triangle_id = ~0) is
+ * not traced again -- it passes through unchanged with a (0,0,0,0) pixel.  The reference has no such test: it
+ * reflects every record, and since a miss stores normal := direction (tracekernel.ck:282-283) and leaves
+ * `direction` unwritten, it sends those rays straight back where they came from. */
 int rt_trace_pass(const rt_scene *scene, const void *rays_in_dev, void *rays_out_dev, float *rgba_dev, size_t n,
                   const float cam[16], unsigned trace_operation, void *stream);
 
