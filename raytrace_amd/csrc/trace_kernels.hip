@@ -34,6 +34,32 @@ constexpr uint32_t kDone = 0xFFFFFFFFu;
 
 __device__ __forceinline__ float4 LoadF4(const float4 *p) { return *p; }
 
+// Ray records are read once and hit records written once per launch, while node and triangle records are read
+// over and over: the streams are marked non-temporal so that they do not push the scene out of the 4 MB L2 of
+// an XCD (scenes of a few MB sit right at that size).
+#ifndef RT_STREAM_NT
+#define RT_STREAM_NT 1
+#endif
+typedef float NativeF4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 LoadStreamF4(const float4 *p)
+{
+#if RT_STREAM_NT
+  const NativeF4 v = __builtin_nontemporal_load(reinterpret_cast<const NativeF4 *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void StoreStreamF4(float4 *p, const float4 v)
+{
+#if RT_STREAM_NT
+  const NativeF4 n = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(n, reinterpret_cast<NativeF4 *>(p));
+#else
+  *p = v;
+#endif
+}
+
 struct Best {
   float t, u, v;
   uint32_t id;
@@ -269,15 +295,15 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) ClosestHitKernel(K
         in_o = make_float4(p.cam[0], p.cam[1], p.cam[2], 1.f);
         in_d = make_float4(tx / len, ty / len, tz / len, 0.f);
       } else {
-        in_o = LoadF4(rp);
-        in_d = LoadF4(rp + 1);
+        in_o = LoadStreamF4(rp);
+        in_d = LoadStreamF4(rp + 1);
       }
       float ox = in_o.x, oy = in_o.y, oz = in_o.z, dx = in_d.x, dy = in_d.y, dz = in_d.z;
       bool live = true;
       if (MODE == kModeTrace) {
         if (p.op == 1u) {
           // reflect about the stored normal and step off the surface (tracekernel.ck:101-104,227-233)
-          const float4 nn = LoadF4(rp + 2);
+          const float4 nn = LoadStreamF4(rp + 2);
           const float s = 2.0f * Dot4(in_d, nn);
           dx = in_d.x - s * nn.x; dy = in_d.y - s * nn.y; dz = in_d.z - s * nn.z;
           ox = in_o.x + nn.x * 0.00001f; oy = in_o.y + nn.y * 0.00001f; oz = in_o.z + nn.z * 0.00001f;
@@ -340,15 +366,14 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) ClosestHitKernel(K
       if (p.hits16) {
         rt_hit16 h;
         h.triangle_id = best.id; h.t = best.t; h.u = hit ? best.u : 0.f; h.v = hit ? best.v : 0.f;
-        *reinterpret_cast<float4 *>(p.hits16 + idx) =
-            make_float4(__uint_as_float(h.triangle_id), h.t, h.u, h.v);
+        StoreStreamF4(reinterpret_cast<float4 *>(p.hits16 + idx), make_float4(__uint_as_float(h.triangle_id), h.t, h.u, h.v));
       }
       float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
       if (p.hits || (MODE == kModeTrace && p.rgba)) {
         float4 out_o = in_o, out_n = in_d, out_d = in_d;
         float out_u = 0.f, out_v = 0.f;
         if (MODE == kModeTrace && !live) {
-          out_n = LoadF4(rp + 2);  // terminated record passes through unchanged
+          out_n = LoadStreamF4(rp + 2);  // terminated record passes through unchanged
         }
         if (hit) {
           const rt_face f = p.faces[best.id];
@@ -392,7 +417,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) ClosestHitKernel(K
         rec0 = out_o; rec1 = out_d; rec2 = out_n;
         rec3 = make_float4(out_u, out_v, __uint_as_float(best.id), best.t);
       }
-      if (MODE == kModeTrace && p.rgba) reinterpret_cast<float4 *>(p.rgba)[idx] = color;
+      if (MODE == kModeTrace && p.rgba) StoreStreamF4(reinterpret_cast<float4 *>(p.rgba) + idx, color);
     }
     if (p.hits) {
       // 64-byte records, one per lane: written straight from the lanes, every store instruction would scatter 64
@@ -412,7 +437,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) ClosestHitKernel(K
         const uint32_t src = k * 16u + (lane >> 2), quarter = lane & 3u;
         const float4 v = tile[src * 4u + (quarter ^ ((src >> 2) & 3u))];
         uint32_t src_idx;
-        if (RayOfLane(p, pos, src, src_idx)) reinterpret_cast<float4 *>(p.hits + src_idx)[quarter] = v;
+        if (RayOfLane(p, pos, src, src_idx)) StoreStreamF4(reinterpret_cast<float4 *>(p.hits + src_idx) + quarter, v);
       }
       if (p.cursor) {   // the next round's pushes must not overtake this round's reads of the exchange tile
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
