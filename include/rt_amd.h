@@ -209,14 +209,17 @@ int rt_scene_count_fetches(const rt_scene *s, const rt_ray_isect *rays_host, siz
                            uint64_t counts[6], uint32_t *per_ray);
 /* Planning aid: a host-side lockstep model of one 64-lane wave running the traversal (a phase lasts as
  * long as its slowest lane).  Samples `max_waves` waves (0 = all) over the ray stream and returns
- * out[0..9] = {waves, rays, wave node steps, useful lane node steps, wave triangle steps, useful lane
+ * out[0..13] = {waves, rays, wave node steps, useful lane node steps, wave triangle steps, useful lane
  * triangle steps, wave leaf phases, lanes in leaf phases, refill events, lanes refilled, steps of the longest
- * wave}.  policy 0 = descend until every lane holds a leaf, then test leaves; 1 = one node step and one
- * leaf test per iteration.  refill = 0
+ * wave, node steps in which all lanes visit one node, loop iterations (each exposes one memory latency), iterations
+ * of the longest wave}; out[14..15] are zero.  policy 0 = descend until every lane holds a leaf, then test leaves;
+ * 1 = one node step and one leaf test per iteration; 2..100 = leave the node loop once that percentage of the busy
+ * lanes holds a leaf (the kernel's "leaf_pct"); -k = fused iterations: the lanes at inner nodes take a node step while,
+ * in the same iteration, the lanes at leaves test up to k triangles.  refill = 0
  * models one batch of 64 rays per wave; refill = k models a wave that takes new rays for its idle
  * lanes whenever k or more lanes have finished.  Computes no hits. */
 int rt_scene_wave_model(const rt_scene *s, const rt_ray_isect *rays_host, size_t n, unsigned image_width, unsigned refill,
-                        size_t max_waves, int policy, uint64_t out[12]);
+                        size_t max_waves, int policy, uint64_t out[16]);
 /* The same counters taken on the device by an instrumented build of the kernel over all n
  * rays (device pointer): counts[0..3] as above, counts[4] = n, counts[5] = the deepest traversal stack
  * (entries) any ray reached. */

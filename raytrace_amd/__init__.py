@@ -312,10 +312,11 @@ class Scene:
 
     def wave_model(self, rays, image_width=0, refill=0, max_waves=0, policy=0):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, RAY_FLOATS)
-        v = (C.c_uint64 * 12)()
+        v = (C.c_uint64 * 16)()
         _check(lib.rt_scene_wave_model(self._h, _ptr(rays), len(rays), image_width, refill, max_waves, policy, v))
         keys = ["waves", "rays", "wave_node_steps", "lane_node_steps", "wave_tri_steps", "lane_tri_steps",
-                "wave_leaf_phases", "lane_leaf_phases", "refills", "refill_lanes", "max_wave_steps", "uniform_node_steps"]
+                "wave_leaf_phases", "lane_leaf_phases", "refills", "refill_lanes", "max_wave_steps", "uniform_node_steps",
+                "iterations", "max_wave_iterations"]
         return dict(zip(keys, [int(x) for x in v]))
 
     def wave_timeline(self, rays_ptr, n):

@@ -1051,13 +1051,14 @@ int rt_scene_count_fetches(const rt_scene *s, const rt_ray_isect *rays_host, siz
 }
 
 int rt_scene_wave_model(const rt_scene *s, const rt_ray_isect *rays_host, size_t n, unsigned image_width, unsigned refill,
-                        size_t max_waves, int policy, uint64_t out[12])
+                        size_t max_waves, int policy, uint64_t out[16])
 {
   if (!s || !rays_host || !out) return Fail(RT_ERR_INVALID, "null argument");
   if (image_width && n % image_width) return Fail(RT_ERR_INVALID, "ray count is not a multiple of image_width");
   rt::WaveModel m = rt::SimulateWaves(s->flat, s->width, s->quant != 0, rays_host, n, image_width, refill, max_waves, policy);
   out[0] = m.waves; out[1] = m.rays; out[2] = m.wave_node_steps; out[3] = m.lane_node_steps; out[4] = m.wave_tri_steps;
   out[5] = m.lane_tri_steps; out[6] = m.wave_leaf_phases; out[7] = m.lane_leaf_phases; out[8] = m.refills; out[9] = m.refill_lanes; out[10] = m.max_wave_steps; out[11] = m.uniform_node_steps;
+  out[12] = m.iterations; out[13] = m.max_wave_iterations; out[14] = out[15] = 0;
   return RT_OK;
 }
 

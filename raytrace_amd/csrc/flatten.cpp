@@ -348,6 +348,7 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
     for (auto &l : lanes) assign(l);
     m.waves++;
     const uint64_t wave_steps_before = m.wave_node_steps + m.wave_tri_steps;
+    uint64_t wave_iterations = 0;   // loop iterations of this wave = memory latencies it exposes
     for (;;) {
       // retire / refill
       uint32_t idle = 0, active = 0;
@@ -377,11 +378,44 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
       }
       if (active == 0) {
         m.max_wave_steps = std::max(m.max_wave_steps, m.wave_node_steps + m.wave_tri_steps - wave_steps_before);
+        m.max_wave_iterations = std::max(m.max_wave_iterations, wave_iterations);
         break;
       }
+      if (policy < 0) {
+        // fused iteration: the lanes holding an inner reference take one node step and, in the same iteration, the
+        // lanes parked at a leaf test up to -policy of its triangles (both kinds of record are fetched together, so
+        // the iteration exposes one memory latency); a lane does one kind of work per iteration
+        const uint32_t per_iter = static_cast<uint32_t>(-policy);
+        uint32_t n_inner = 0, n_leaf = 0, maxk = 0;
+        for (auto &l : lanes) { if (!(l.cur & kLeafBit)) n_inner++; else if (l.cur != kDoneRef) n_leaf++; }
+        m.iterations++;
+        wave_iterations++;
+        for (auto &l : lanes) {
+          if (l.cur == kDoneRef) continue;
+          if (!(l.cur & kLeafBit)) {
+            uint32_t hit_ref[4]; float hit_t[4];
+            const int nh = TestNodeHost(fs, width, quant, l.r, l.rq, l.cur, l.tbest, hit_ref, hit_t);
+            l.cur = DescendHost(l.stack, hit_ref, hit_t, nh, l.tbest);
+            continue;
+          }
+          const uint32_t first = (l.cur & ~kLeafBit) >> 3, cnt = l.cur & 7u, now = std::min(cnt, per_iter);
+          maxk = std::max(maxk, now);
+          m.lane_tri_steps += now;
+          for (uint32_t j = 0; j < now; ++j) {
+            GpuTri const &g = fs.tris[first + j];
+            float t, u, v;
+            if (TriTest(g.ax, g.ay, g.az, g.e1x, g.e1y, g.e1z, g.e2x, g.e2y, g.e2z, l.r, t, u, v) &&
+                (t < l.tbest || (t == l.tbest && g.id < l.best))) { l.tbest = t; l.best = g.id; }
+          }
+          if (cnt > now) l.cur = kLeafBit | ((first + now) << 3) | (cnt - now);
+          else l.cur = PopHost(l.stack, l.tbest);
+        }
+        if (n_inner) { m.wave_node_steps++; m.lane_node_steps += n_inner; }
+        if (n_leaf) { m.wave_leaf_phases++; m.lane_leaf_phases += n_leaf; }
+        m.wave_tri_steps += maxk;
+        continue;
+      }
       // node phase: until no lane holds an inner reference
-      uint64_t steps_this_wave_before = m.wave_node_steps + m.wave_tri_steps;
-      (void)steps_this_wave_before;
       for (int node_iter = 0;; ++node_iter) {
         if (policy == 1 && node_iter == 1) break;  // if-if: one node step, then the leaf part, every iteration
         uint32_t n_inner = 0, n_leaf = 0;
@@ -391,6 +425,8 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
         if (policy >= 2 && n_leaf * 100u >= static_cast<uint32_t>(policy) * (n_inner + n_leaf)) break;
         m.wave_node_steps++;
         m.lane_node_steps += n_inner;
+        m.iterations++;
+        wave_iterations++;
         {
           uint32_t first_ref = kDoneRef;
           bool same = true;
@@ -412,6 +448,10 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
       uint32_t maxcnt = 0, nleaf = 0;
       for (auto &l : lanes) if (l.cur != kDoneRef && (l.cur & kLeafBit)) { maxcnt = std::max(maxcnt, l.cur & 7u); nleaf++; }
       if (nleaf) { m.wave_leaf_phases++; m.lane_leaf_phases += nleaf; }
+      if (nleaf) {   // the kernel fetches a leaf's records two at a time: one exposed latency per pair
+        m.iterations += (maxcnt + 1u) / 2u;
+        wave_iterations += (maxcnt + 1u) / 2u;
+      }
       m.wave_tri_steps += maxcnt;
       for (auto &l : lanes) {
         if (l.cur == kDoneRef || !(l.cur & kLeafBit)) continue;

@@ -181,6 +181,8 @@ struct WaveModel {
   uint64_t refills = 0, refill_lanes = 0;
   uint64_t max_wave_steps = 0;  // node + triangle steps of the longest wave
   uint64_t uniform_node_steps = 0;  // node steps in which every participating lane visits the same node
+  uint64_t iterations = 0;          // loop iterations (each exposes one memory latency), all waves
+  uint64_t max_wave_iterations = 0; // ... of the wave that needs most
 };
 WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect const *rays, size_t nrays,
                         uint32_t img_w, uint32_t refill, size_t max_waves, int policy);

@@ -65,13 +65,14 @@ struct Best {
   uint32_t id;
 };
 
+// The records of a leaf are fetched two at a time, before either is tested, so a leaf of up to two triangles exposes
+// one memory latency and a full leaf two, instead of one per triangle (a leaf's records are consecutive).
 template <bool COUNT>
 __device__ __forceinline__ void LeafTest(const KernelArgs &p, const RayCtx &r, uint32_t ref, Best &b, uint32_t &ntri)
 {
   const uint32_t first = (ref & 0x7FFFFFFFu) >> 3, cnt = ref & 7u;
   const float4 *tp = p.tris + static_cast<size_t>(first) * 3u;
-  for (uint32_t j = 0; j < cnt; ++j) {
-    const float4 a = LoadF4(tp + 3 * j), e1 = LoadF4(tp + 3 * j + 1), e2 = LoadF4(tp + 3 * j + 2);
+  auto test = [&](const float4 &a, const float4 &e1, const float4 &e2) {
     float t, u, v;
     const bool ok = TriTest(a.x, a.y, a.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z, r, t, u, v);
     const uint32_t id = __float_as_uint(a.w);
@@ -79,6 +80,14 @@ __device__ __forceinline__ void LeafTest(const KernelArgs &p, const RayCtx &r, u
       b.t = t; b.u = u; b.v = v; b.id = id;
     }
     if (COUNT) ntri++;
+  };
+  for (uint32_t j = 0; j < cnt; j += 2u, tp += 6) {
+    const float4 a0 = LoadF4(tp), b0 = LoadF4(tp + 1), c0 = LoadF4(tp + 2);
+    float4 a1, b1, c1;
+    const bool two = j + 1u < cnt;
+    if (two) { a1 = LoadF4(tp + 3); b1 = LoadF4(tp + 4); c1 = LoadF4(tp + 5); }
+    test(a0, b0, c0);
+    if (two) test(a1, b1, c1);
   }
 }
 
@@ -180,12 +189,39 @@ __device__ __forceinline__ uint32_t NodeStep(const KernelArgs &p, const RayCtx &
       const bool h1 = SlabTestQ(q, c1.x, c1.y, c1.z, tbest, t1);
       return Descend2(st, deep, h0, h1, t0, t1, c0.w, c1.w, tbest);
     }
-    const uint4 c0 = np[0], c1 = np[1], c2 = np[2], c3 = np[3];
+#if RT_EXP_DUP_LOADS
+    // sensitivity experiment: the node's four 16-byte loads issued twice (the extra set first, so it returns first
+    // and adds no latency of its own, only work for the vector-memory path)
+    typedef uint32_t NativeU4 __attribute__((ext_vector_type(4)));
+    NativeU4 d0, d1, d2, d3;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(np) : "memory");
+#endif
+    uint4 c0 = np[0], c1 = np[1], c2 = np[2], c3 = np[3];
+    // the child references travel with the boxes in four 16-byte loads: without this the compiler splits them off
+    // into four dependent 4-byte loads issued after the box tests, a second memory latency in every step
+    asm volatile("" : "+v"(c0.w), "+v"(c1.w), "+v"(c2.w), "+v"(c3.w));
     float t0, t1, t2, t3;
+#if RT_EXP_DUP_VALU
+    {   // sensitivity experiment: the vector work of four more slab tests (24 permutes, 24 fused multiply-adds, 16 min/max)
+      float x0 = tbest, x1 = q.ax, x2 = q.ay, x3 = q.az;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        asm volatile("v_perm_b32 %0, %0, %1, %2\n\tv_perm_b32 %1, %1, %2, %3\n\tv_perm_b32 %2, %2, %3, %0\n\tv_perm_b32 %3, %3, %0, %1\n\t"
+                     "v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %1, %1, %2, %3\n\tv_fma_f32 %2, %2, %3, %0\n\tv_fma_f32 %3, %3, %0, %1\n\t"
+                     "v_max_f32 %0, %0, %1\n\tv_min3_f32 %1, %1, %2, %3\n\tv_max3_f32 %2, %2, %3, %0"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+      asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+    }
+#endif
     const bool h0 = SlabTestQ(q, c0.x, c0.y, c0.z, tbest, t0);
     const bool h1 = SlabTestQ(q, c1.x, c1.y, c1.z, tbest, t1);
     const bool h2 = SlabTestQ(q, c2.x, c2.y, c2.z, tbest, t2);
     const bool h3 = SlabTestQ(q, c3.x, c3.y, c3.z, tbest, t3);
+#if RT_EXP_DUP_LOADS
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(d0), "v"(d1), "v"(d2), "v"(d3) : "memory");
+#endif
     return Descend4(st, deep, h0, h1, h2, h3, t0, t1, t2, t3, c0.w, c1.w, c2.w, c3.w, tbest);
   }
   if (WIDTH == 2) {
@@ -232,7 +268,7 @@ __device__ __forceinline__ bool RayOfLane(const KernelArgs &p, const UnitPos &u,
 }
 
 #ifndef RT_MIN_WAVES_PER_SIMD
-#define RT_MIN_WAVES_PER_SIMD 1
+#define RT_MIN_WAVES_PER_SIMD 7
 #endif
 template <int WIDTH, bool QUANT, int MODE, bool COUNT>
 __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) ClosestHitKernel(KernelArgs p)
