@@ -39,7 +39,10 @@ def test_sharded_render_equals_single_launch(rt, gpu, shape):
         tx, ty = tile_grid(W, H, tile)
         for G in (2, 3, 8):
             lists = assign_tiles(tx * ty, G, costs)
-            assert balance(lists, costs) < balance(assign_tiles(tx * ty, G, None), costs) + 1e-9
+            # greedy by measured cost: within 5 % of perfect balance, and never worse than dealing the squares round-robin
+            # by more than the greedy rule's own granularity (on a small image round-robin can land within 0.01 % by luck)
+            assert balance(lists, costs) <= 1.05
+            assert balance(lists, costs) <= balance(assign_tiles(tx * ty, G, None), costs) + 0.01
             gather = torch.full((W * H, 4), -3.0, dtype=torch.float32, device="cuda")
             ids_all, first_all, base = [], [], 0
             # a rank's rays are whole squares, each `tile` wide when the width divides evenly: an image one square wide
