@@ -421,6 +421,29 @@ def main():
             other = {"bvh": "sah", "ms_per_step": round(sms, 4), "value": round(n_local / (sms * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
             scene_s.close()
 
+        # the same steps issued alternately on two streams (two frames in flight, each with its own hit buffer): the tail of
+        # one launch overlaps the head of the next.  Reported beside `value`, never as it: launches overlap, so there is no
+        # per-launch duration to hold against a profile.
+        overlapped = None
+        if world == 1 and W and not sharded and workload != "mirror5" and a.raygen == "table":
+            s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+            hits2 = [hits_d, torch.empty_like(hits_d)]
+            k_no = [0]
+
+            def step_2():
+                i = k_no[0] & 1
+                k_no[0] += 1
+                out = hits2[i].data_ptr()
+                scene.intersect_async(tables[k_no[0] % len(tables)].data_ptr(), n_local, out if full_out else None,
+                                      None if full_out else out, s2[i].cuda_stream)
+            for _ in range(a.warmup):
+                step_2()
+            w_2, _ = timed(None, a.steps, step_2)
+            ms2 = w_2 * 1e3 / max(1, a.steps)
+            overlapped = {"streams": 2, "ms_per_step": round(ms2, 4), "value": round(n_local / (ms2 * 1e-3) / 1e6, 1), "unit": "Mrays/s",
+                          "what": "the same launches issued alternately on two streams, two frames in flight"}
+            del hits2
+
         # the drop-in call with HOST buffers (pageable memory both ways): PCIe-inclusive, reported beside `value`, never as it
         host_call = None
         if world == 1 and W and not sharded and workload != "mirror5" and full_out:
@@ -491,7 +514,8 @@ def main():
                        else "image centre first",
                        "parallelism": f"{world} x one process per GPU, " + ("cost-balanced image squares + RCCL gather + device scatter"
                                                                             if sharded else "frame-parallel")},
-            "roofline": roofline, "cpu_baseline": cpu, "same_launch_on_sah_tree": other, "host_pointer_call": host_call,
+            "roofline": roofline, "cpu_baseline": cpu, "same_launch_on_sah_tree": other, "two_frames_in_flight": overlapped,
+            "host_pointer_call": host_call,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)

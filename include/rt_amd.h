@@ -209,10 +209,10 @@ int rt_scene_count_fetches(const rt_scene *s, const rt_ray_isect *rays_host, siz
                            uint64_t counts[6], uint32_t *per_ray);
 /* Planning aid: a host-side lockstep model of one 64-lane wave running the traversal (a phase lasts as
  * long as its slowest lane).  Samples `max_waves` waves (0 = all) over the ray stream and returns
- * out[0..13] = {waves, rays, wave node steps, useful lane node steps, wave triangle steps, useful lane
+ * out[0..15] = {waves, rays, wave node steps, useful lane node steps, wave triangle steps, useful lane
  * triangle steps, wave leaf phases, lanes in leaf phases, refill events, lanes refilled, steps of the longest
  * wave, node steps in which all lanes visit one node, loop iterations (each exposes one memory latency), iterations
- * of the longest wave}; out[14..15] are zero.  policy 0 = descend until every lane holds a leaf, then test leaves;
+ * of the longest wave, node steps whose lanes visit exactly two different nodes, ... exactly three}.  policy 0 = descend until every lane holds a leaf, then test leaves;
  * 1 = one node step and one leaf test per iteration; 2..100 = leave the node loop once that percentage of the busy
  * lanes holds a leaf (the kernel's "leaf_pct"); -k = fused iterations: the lanes at inner nodes take a node step while,
  * in the same iteration, the lanes at leaves test up to k triangles.  refill = 0

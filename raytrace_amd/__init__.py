@@ -316,7 +316,7 @@ class Scene:
         _check(lib.rt_scene_wave_model(self._h, _ptr(rays), len(rays), image_width, refill, max_waves, policy, v))
         keys = ["waves", "rays", "wave_node_steps", "lane_node_steps", "wave_tri_steps", "lane_tri_steps",
                 "wave_leaf_phases", "lane_leaf_phases", "refills", "refill_lanes", "max_wave_steps", "uniform_node_steps",
-                "iterations", "max_wave_iterations"]
+                "iterations", "max_wave_iterations", "two_node_steps", "three_node_steps"]
         return dict(zip(keys, [int(x) for x in v]))
 
     def wave_timeline(self, rays_ptr, n):

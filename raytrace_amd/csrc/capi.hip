@@ -1058,7 +1058,7 @@ int rt_scene_wave_model(const rt_scene *s, const rt_ray_isect *rays_host, size_t
   rt::WaveModel m = rt::SimulateWaves(s->flat, s->width, s->quant != 0, rays_host, n, image_width, refill, max_waves, policy);
   out[0] = m.waves; out[1] = m.rays; out[2] = m.wave_node_steps; out[3] = m.lane_node_steps; out[4] = m.wave_tri_steps;
   out[5] = m.lane_tri_steps; out[6] = m.wave_leaf_phases; out[7] = m.lane_leaf_phases; out[8] = m.refills; out[9] = m.refill_lanes; out[10] = m.max_wave_steps; out[11] = m.uniform_node_steps;
-  out[12] = m.iterations; out[13] = m.max_wave_iterations; out[14] = out[15] = 0;
+  out[12] = m.iterations; out[13] = m.max_wave_iterations; out[14] = m.two_node_steps; out[15] = m.three_node_steps;
   return RT_OK;
 }
 

@@ -436,6 +436,19 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
               else if (l.cur != first_ref) same = false;
             }
           if (same) m.uniform_node_steps++;
+          else {
+            // how many different nodes the stepping lanes hold (2 and 3 counted: candidates for a per-node scalar fetch)
+            uint32_t seen_refs[4];
+            int distinct = 0;
+            for (auto &l : lanes) {
+              if (l.cur & kLeafBit) continue;
+              bool known = false;
+              for (int k = 0; k < distinct && k < 4; ++k) known = known || seen_refs[k] == l.cur;
+              if (!known) { if (distinct < 4) seen_refs[distinct] = l.cur; ++distinct; if (distinct > 3) break; }
+            }
+            if (distinct == 2) m.two_node_steps++;
+            else if (distinct == 3) m.three_node_steps++;
+          }
         }
         for (auto &l : lanes) {
           if (l.cur & kLeafBit) continue;

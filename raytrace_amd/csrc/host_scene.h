@@ -181,6 +181,7 @@ struct WaveModel {
   uint64_t refills = 0, refill_lanes = 0;
   uint64_t max_wave_steps = 0;  // node + triangle steps of the longest wave
   uint64_t uniform_node_steps = 0;  // node steps in which every participating lane visits the same node
+  uint64_t two_node_steps = 0, three_node_steps = 0;  // node steps whose lanes visit exactly two / three different nodes
   uint64_t iterations = 0;          // loop iterations (each exposes one memory latency), all waves
   uint64_t max_wave_iterations = 0; // ... of the wave that needs most
 };

@@ -174,6 +174,27 @@ __device__ __forceinline__ uint32_t Descend4(Stack &st, uint2 *deep, bool h0, bo
   return next;
 }
 
+#ifndef RT_SCALAR_NODE
+#define RT_SCALAR_NODE 1
+#endif
+// Node step of a whole wave at ONE four-wide quantized node (every stepping lane holds the same reference, as at the
+// top of the tree): the 64-byte record is fetched once through the scalar cache into SGPRs instead of 64 times through
+// the vector-memory path, which is the busiest unit of this kernel.
+typedef uint32_t ScalarNode __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ uint32_t NodeStepUniformQ4(const KernelArgs &p, const RayCtxQ &q, uint32_t node, float tbest, Stack &st,
+                                                      uint2 *deep)
+{
+  const uint4 *np = reinterpret_cast<const uint4 *>(p.nodes) + static_cast<size_t>(node) * 4u;
+  ScalarNode w;
+  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(np) : "memory");
+  float t0, t1, t2, t3;
+  const bool h0 = SlabTestQ(q, w[0], w[1], w[2], tbest, t0);
+  const bool h1 = SlabTestQ(q, w[4], w[5], w[6], tbest, t1);
+  const bool h2 = SlabTestQ(q, w[8], w[9], w[10], tbest, t2);
+  const bool h3 = SlabTestQ(q, w[12], w[13], w[14], tbest, t3);
+  return Descend4(st, deep, h0, h1, h2, h3, t0, t1, t2, t3, w[3], w[7], w[11], w[15], tbest);
+}
+
 // One step at a node of the selected layout: returns the next reference to visit (kDone if the stack ran dry).
 template <int WIDTH, bool QUANT>
 __device__ __forceinline__ uint32_t NodeStep(const KernelArgs &p, const RayCtx &r, const RayCtxQ &q, uint32_t cur,
@@ -381,7 +402,15 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) ClosestHitKernel(K
         if (ni != 0u && nl * 100u < p.leaf_pct * (ni + nl)) {
           if (inner) {
             if (COUNT) nnode++;
-            cur = NodeStep<WIDTH, QUANT>(p, r, rq, cur, best.t, st, deep);
+            bool stepped = false;
+            if (RT_SCALAR_NODE && QUANT && WIDTH == 4) {
+              const uint32_t node = __builtin_amdgcn_readfirstlane(cur);   // of the first stepping lane
+              if (__ballot(cur != node) == 0ull) {                        // ... and of all of them
+                cur = NodeStepUniformQ4(p, rq, node, best.t, st, deep);
+                stepped = true;
+              }
+            }
+            if (!stepped) cur = NodeStep<WIDTH, QUANT>(p, r, rq, cur, best.t, st, deep);
             if (COUNT) maxsp = max(maxsp, st.sp);
           }
         } else if (parked) {

@@ -113,6 +113,74 @@ __global__ void __launch_bounds__(64) Chain(float *out, int iters)
 #define OP(k) asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_min3_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(m), "v"(c));
         REP8(OP)
 #undef OP
+      } else if (MODE == 24) {
+#define OP(k) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(sel), "v"(sel));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 25) {
+#define OP(k) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[k]) : "v"(sel));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 26) {
+#define OP(k) asm volatile("v_lshrrev_b32 %0, 16, %0" : "+v"(a[k]));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 27) {
+#define OP(k) asm volatile("v_bfe_u32 %0, %0, 16, 16" : "+v"(a[k]));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 28) {
+#define OP(k) asm volatile("v_alignbit_b32 %0, %1, %0, 16" : "+v"(a[k]) : "v"(sel));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 29) {
+#define OP(k) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[k]) : "v"(sel));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 30) {
+#define OP(k) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[k]) : "v"(sel));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 31) {
+#define OP(k) asm volatile("v_cndmask_b32 %0, %0, %1, s[10:11]" : "+v"(a[k]) : "v"(m));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 32) {
+#define OP(k) asm volatile("v_cmp_le_f32 s[12:13], %0, %1" : : "v"(a[k]), "v"(m) : "s12","s13");
+        REP8(OP)
+#undef OP
+      } else if (MODE == 33) {
+#define OP(k) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a[k]) : "v"(sel));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 34) {
+#define OP(k) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[k]) : "v"(sel));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 35) {
+#define OP(k) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[k]));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 36) {
+#define OP(k) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[k]) : "v"(sel));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 37) {
+#define OP(k) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[k]) : "v"(sel));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 38) {
+#define OP(k) asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_and_or_b32 %0, %0, %3, %3" : "+v"(a[k]) : "v"(m), "v"(c), "v"(sel));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 39) {
+#define OP(k) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[k]));
+        REP8(OP)
+#undef OP
+      } else if (MODE == 40) {
+#define OP(k) asm volatile("v_med3_f32 %0, %0, %1, %2\n\tv_perm_b32 %0, %0, %1, %3" : "+v"(a[k]) : "v"(m), "v"(c), "v"(sel));
+        REP8(OP)
+#undef OP
       }
     }
   }
@@ -175,5 +243,22 @@ int main()
   Run<18>("v_pk_mul_f32", cus, 1);
   Run<20>("fma+perm pair", cus, 2);
   Run<23>("fma+min3 pair", cus, 2);
+  Run<24>("v_and_or_b32", cus, 1);
+  Run<25>("v_or_b32", cus, 1);
+  Run<26>("v_lshrrev_b32", cus, 1);
+  Run<27>("v_bfe_u32", cus, 1);
+  Run<28>("v_alignbit_b32", cus, 1);
+  Run<29>("v_xor_b32", cus, 1);
+  Run<30>("v_min_u32", cus, 1);
+  Run<31>("v_cndmask_b32 sgpr", cus, 1);
+  Run<32>("v_cmp_le_f32 sgpr", cus, 1);
+  Run<33>("v_lshl_or_b32", cus, 1);
+  Run<34>("v_add3_u32", cus, 1);
+  Run<35>("v_cvt_f32_u32", cus, 1);
+  Run<36>("v_sub_u32", cus, 1);
+  Run<37>("v_mul_u32_u24", cus, 1);
+  Run<38>("fma+and_or pair", cus, 2);
+  Run<39>("v_mov_b32_dpp", cus, 1);
+  Run<40>("med3+perm pair", cus, 2);
   return 0;
 }
