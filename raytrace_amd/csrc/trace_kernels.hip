@@ -36,28 +36,31 @@ __device__ __forceinline__ float4 LoadF4(const float4 *p) { return *p; }
 
 // Ray records are read once and hit records written once per launch, while node and triangle records are read
 // over and over: the streams are marked non-temporal so that they do not push the scene out of the 4 MB L2 of
-// an XCD (scenes of a few MB sit right at that size).
+// an XCD (scenes of a few MB sit right at that size).  Not in the full trace step: there a pass reads the records the
+// pass before it wrote (the bounce loop ping-pongs two buffers), and a 1080p frame of them fits the 256 MB
+// Infinity Cache if it is allowed to stay there.
 #ifndef RT_STREAM_NT
 #define RT_STREAM_NT 1
 #endif
 typedef float NativeF4 __attribute__((ext_vector_type(4)));
+template <bool STREAM>
 __device__ __forceinline__ float4 LoadStreamF4(const float4 *p)
 {
-#if RT_STREAM_NT
-  const NativeF4 v = __builtin_nontemporal_load(reinterpret_cast<const NativeF4 *>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-#else
+  if (RT_STREAM_NT && STREAM) {
+    const NativeF4 v = __builtin_nontemporal_load(reinterpret_cast<const NativeF4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
   return *p;
-#endif
 }
+template <bool STREAM>
 __device__ __forceinline__ void StoreStreamF4(float4 *p, const float4 v)
 {
-#if RT_STREAM_NT
-  const NativeF4 n = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(n, reinterpret_cast<NativeF4 *>(p));
-#else
+  if (RT_STREAM_NT && STREAM) {
+    const NativeF4 n = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(n, reinterpret_cast<NativeF4 *>(p));
+    return;
+  }
   *p = v;
-#endif
 }
 
 struct Best {
@@ -184,7 +187,8 @@ typedef uint32_t ScalarNode __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ uint32_t NodeStepUniformQ4(const KernelArgs &p, const RayCtxQ &q, uint32_t node, float tbest, Stack &st,
                                                       uint2 *deep)
 {
-  const uint4 *np = reinterpret_cast<const uint4 *>(p.nodes) + static_cast<size_t>(node) * 4u;
+  // `node` is wave-uniform by contract; the intrinsic makes that a fact for the compiler, whatever it merged around the call
+  const uint4 *np = reinterpret_cast<const uint4 *>(p.nodes) + static_cast<size_t>(__builtin_amdgcn_readfirstlane(node)) * 4u;
   ScalarNode w;
   asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(np) : "memory");
   float t0, t1, t2, t3;
@@ -291,8 +295,13 @@ __device__ __forceinline__ bool RayOfLane(const KernelArgs &p, const UnitPos &u,
 #ifndef RT_MIN_WAVES_PER_SIMD
 #define RT_MIN_WAVES_PER_SIMD 7
 #endif
+// Resident waves per SIMD the register allocation is held to: 7 (72 VGPRs) for the intersection kernels; the full trace
+// step carries the camera / reflection setup and the pixel and needs 80 VGPRs to stay out of private memory, so it runs at 6
+// (at 7 it spills inside the loop and loses a quarter of its speed).
+constexpr int MinWavesPerSimd(int mode) { return mode == kModeTrace ? (RT_MIN_WAVES_PER_SIMD < 6 ? RT_MIN_WAVES_PER_SIMD : 6) : RT_MIN_WAVES_PER_SIMD; }
+
 template <int WIDTH, bool QUANT, int MODE, bool COUNT>
-__global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) ClosestHitKernel(KernelArgs p)
+__global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(KernelArgs p)
 {
   extern __shared__ uint2 lds_stack[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -352,15 +361,15 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) ClosestHitKernel(K
         in_o = make_float4(p.cam[0], p.cam[1], p.cam[2], 1.f);
         in_d = make_float4(tx / len, ty / len, tz / len, 0.f);
       } else {
-        in_o = LoadStreamF4(rp);
-        in_d = LoadStreamF4(rp + 1);
+        in_o = LoadStreamF4<MODE != kModeTrace>(rp);
+        in_d = LoadStreamF4<MODE != kModeTrace>(rp + 1);
       }
       float ox = in_o.x, oy = in_o.y, oz = in_o.z, dx = in_d.x, dy = in_d.y, dz = in_d.z;
       bool live = true;
       if (MODE == kModeTrace) {
         if (p.op == 1u) {
           // reflect about the stored normal and step off the surface (tracekernel.ck:101-104,227-233)
-          const float4 nn = LoadStreamF4(rp + 2);
+          const float4 nn = LoadStreamF4<MODE != kModeTrace>(rp + 2);
           const float s = 2.0f * Dot4(in_d, nn);
           dx = in_d.x - s * nn.x; dy = in_d.y - s * nn.y; dz = in_d.z - s * nn.z;
           ox = in_o.x + nn.x * 0.00001f; oy = in_o.y + nn.y * 0.00001f; oz = in_o.z + nn.z * 0.00001f;
@@ -405,7 +414,8 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) ClosestHitKernel(K
             bool stepped = false;
             if (RT_SCALAR_NODE && QUANT && WIDTH == 4) {
               const uint32_t node = __builtin_amdgcn_readfirstlane(cur);   // of the first stepping lane
-              if (__ballot(cur != node) == 0ull) {                        // ... and of all of them
+              const unsigned long long others = __ballot(cur != node);
+              if (others == 0ull) {                                       // ... and of all of them
                 cur = NodeStepUniformQ4(p, rq, node, best.t, st, deep);
                 stepped = true;
               }
@@ -431,14 +441,14 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) ClosestHitKernel(K
       if (p.hits16) {
         rt_hit16 h;
         h.triangle_id = best.id; h.t = best.t; h.u = hit ? best.u : 0.f; h.v = hit ? best.v : 0.f;
-        StoreStreamF4(reinterpret_cast<float4 *>(p.hits16 + idx), make_float4(__uint_as_float(h.triangle_id), h.t, h.u, h.v));
+        StoreStreamF4<MODE != kModeTrace>(reinterpret_cast<float4 *>(p.hits16 + idx), make_float4(__uint_as_float(h.triangle_id), h.t, h.u, h.v));
       }
       float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
       if (p.hits || (MODE == kModeTrace && p.rgba)) {
         float4 out_o = in_o, out_n = in_d, out_d = in_d;
         float out_u = 0.f, out_v = 0.f;
         if (MODE == kModeTrace && !live) {
-          out_n = LoadStreamF4(rp + 2);  // terminated record passes through unchanged
+          out_n = LoadStreamF4<MODE != kModeTrace>(rp + 2);  // terminated record passes through unchanged
         }
         if (hit) {
           const rt_face f = p.faces[best.id];
@@ -482,7 +492,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) ClosestHitKernel(K
         rec0 = out_o; rec1 = out_d; rec2 = out_n;
         rec3 = make_float4(out_u, out_v, __uint_as_float(best.id), best.t);
       }
-      if (MODE == kModeTrace && p.rgba) StoreStreamF4(reinterpret_cast<float4 *>(p.rgba) + idx, color);
+      if (MODE == kModeTrace && p.rgba) StoreStreamF4<MODE != kModeTrace>(reinterpret_cast<float4 *>(p.rgba) + idx, color);
     }
     if (p.hits) {
       // 64-byte records, one per lane: written straight from the lanes, every store instruction would scatter 64
@@ -502,7 +512,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES_PER_SIMD) ClosestHitKernel(K
         const uint32_t src = k * 16u + (lane >> 2), quarter = lane & 3u;
         const float4 v = tile[src * 4u + (quarter ^ ((src >> 2) & 3u))];
         uint32_t src_idx;
-        if (RayOfLane(p, pos, src, src_idx)) StoreStreamF4(reinterpret_cast<float4 *>(p.hits + src_idx) + quarter, v);
+        if (RayOfLane(p, pos, src, src_idx)) StoreStreamF4<MODE != kModeTrace>(reinterpret_cast<float4 *>(p.hits + src_idx) + quarter, v);
       }
       if (p.cursor) {   // the next round's pushes must not overtake this round's reads of the exchange tile
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
