@@ -73,7 +73,8 @@ def parse():
                          "centroid indexing repaired (fixed, the default), or the surface-area build in the same node format (sah)")
     ap.add_argument("--out", default="full", choices=["full", "compact"], help="64-byte hit records or 16-byte {id,t,u,v}")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-compare", action="store_true", help="skip the extra timing on the surface-area tree")
+    ap.add_argument("--no-compare", action="store_true",
+                    help="skip the extra timings beside the headline (surface-area tree, two streams, host-pointer call): profiling runs")
     ap.add_argument("--cpu-stride", type=int, default=4, help="sub-grid stride (both axes) of the CPU baseline sample")
     ap.add_argument("--tile", type=int, default=64, help="tiles4k: side of the squares dealt to the ranks (multiple of 8)")
     ap.add_argument("--assign", default="cost", choices=["cost", "roundrobin"], help="tiles4k: how squares are dealt to ranks")
@@ -425,7 +426,7 @@ def main():
         # one launch overlaps the head of the next.  Reported beside `value`, never as it: launches overlap, so there is no
         # per-launch duration to hold against a profile.
         overlapped = None
-        if world == 1 and W and not sharded and workload != "mirror5" and a.raygen == "table":
+        if world == 1 and W and not sharded and workload != "mirror5" and a.raygen == "table" and not a.no_compare:
             s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
             hits2 = [hits_d, torch.empty_like(hits_d)]
             k_no = [0]
@@ -446,7 +447,7 @@ def main():
 
         # the drop-in call with HOST buffers (pageable memory both ways): PCIe-inclusive, reported beside `value`, never as it
         host_call = None
-        if world == 1 and W and not sharded and workload != "mirror5" and full_out:
+        if world == 1 and W and not sharded and workload != "mirror5" and full_out and not a.no_compare:
             hits_h = np.zeros_like(rays_h)
             for _ in range(2):
                 rt._check(rt.lib.ray_scene_intersection(rt._ptr(rays_h), n_local, scene._h, rt._ptr(hits_h)))

@@ -103,8 +103,8 @@ int rt_ao_rays(const rt_mesh *m, const rt_aabb *root, uint64_t seed, size_t firs
  * HIP device ordinal. */
 #define RT_DEVICE_NONE (-1) /* host-only scene: validation, rt_scene_info and rt_scene_count_fetches work;
                                every tracing entry point fails with RT_ERR_DEVICE */
-#define RT_SCENE_WIDE2 0u   /* traverse the 64-byte two-child records  */
-#define RT_SCENE_WIDE4 4u   /* traverse the 128-byte four-child records */
+#define RT_SCENE_WIDE2 0u   /* traverse the two-child records (32 bytes quantized, 64 bytes with float boxes)   */
+#define RT_SCENE_WIDE4 4u   /* traverse the four-child records (64 bytes quantized, 128 bytes with float boxes): the faster layout */
 #define RT_SCENE_FLATTEN_DEVICE 0x100u /* OR-ed in: build the traversal records from the uploaded 80-byte nodes with GPU kernels
                                           (the host then only validates and numbers the tree); the records are bit-identical */
 typedef struct rt_scene rt_scene;
