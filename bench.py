@@ -78,6 +78,12 @@ def parse():
     ap.add_argument("--cpu-stride", type=int, default=4, help="sub-grid stride (both axes) of the CPU baseline sample")
     ap.add_argument("--tile", type=int, default=64, help="tiles4k: side of the squares dealt to the ranks (multiple of 8)")
     ap.add_argument("--assign", default="cost", choices=["cost", "roundrobin"], help="tiles4k: how squares are dealt to ranks")
+    ap.add_argument("--gather", default="hits16", choices=["hits16", "bgra8"],
+                    help="tiles4k: what crosses the GPUs into rank 0's framebuffer: the 16-byte {id,t,u,v} hit of every pixel, or its "
+                         "shaded 8-bit BGRA pixel (the full trace step + rt_pack_bgra8: a quarter of the bytes)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="tiles4k: 1 = the exchange of a frame runs beside the trace of the next one (two frames in flight, "
+                         "double-buffered); 0 = trace, exchange, scatter one after the other")
     ap.add_argument("--image-hint", type=int, default=1, help="declare the ray array as a W-wide image (8x8 tiles per wave)")
     ap.add_argument("--raygen", default="table", choices=["table", "device"],
                     help="table: rays are a RayIntersection array resident in HBM (the reference's interface); device: "
@@ -106,8 +112,9 @@ def newest_profile_table(name):
     return {}, None
 
 
-def timed(dist, steps, fn):
-    """Runs fn() `steps` times between barriers; returns (wall seconds, device ms per step by events on the current stream)."""
+def timed(dist, steps, fn, finish=None):
+    """Runs fn() `steps` times (then finish(), which completes what the steps left in flight) between barriers; returns
+    (wall seconds, device ms per step by events on the current stream)."""
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -117,6 +124,8 @@ def timed(dist, steps, fn):
     ev0.record()
     for _ in range(steps):
         fn()
+    if finish:
+        finish()
     ev1.record()
     torch.cuda.synchronize()
     if dist:
@@ -231,37 +240,87 @@ def main():
         rgba_d = torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
         cam = np.eye(4, dtype=np.float32)
 
-    # ---- sharded image: gather buffer, square lists and the exchange --------------------------------------
+    # ---- sharded image: gather buffers, square lists and the exchange --------------------------------------
     if sharded:
+        pix = a.gather == "bgra8"
+        rec_b = 4 if pix else 16
+
+        def records(nrec):
+            return torch.empty((nrec, 1), dtype=torch.int32, device="cuda") if pix else torch.empty((nrec, 4), dtype=torch.float32, device="cuda")
+
         counts = [len(tl.rays_of_tiles(W, H, a.tile, l)[0]) for l in all_lists]
         bases = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        NB = 2     # frames in flight: the exchange of one runs beside the trace of the next
         if rank == 0:
-            gather_d = torch.empty((W * H, 4), dtype=torch.float32, device="cuda")     # squares of rank 0, 1, ... back to back
-            fb_d = torch.empty((W * H, 4), dtype=torch.float32, device="cuda")         # the row-major framebuffer
+            gather_d = [records(W * H) for _ in range(NB)]       # squares of rank 0, 1, ... back to back
+            fb_d = records(W * H)                                # the row-major framebuffer
             ids_h = np.concatenate(all_lists).astype(np.int32)
             first_h = np.concatenate([tl.rays_of_tiles(W, H, a.tile, l)[1].astype(np.int64) + bases[r]
                                       for r, l in enumerate(all_lists)]).astype(np.int32)
             ids_d, first_d = torch.from_numpy(ids_h).cuda(), torch.from_numpy(first_h).cuda()
-            hits_d = gather_d[:counts[0]]          # rank 0 traces straight into its slice of the gather buffer
-            slices = [gather_d[bases[r]:bases[r + 1]] for r in range(world)]
+            mine = [g[:counts[0]] for g in gather_d]             # rank 0 traces straight into its slice of the gather buffer
+            slices = [[g[bases[r]:bases[r + 1]] for r in range(world)] for g in gather_d]
+        else:
+            mine = [records(n_local) for _ in range(NB)]
+        hits_d = mine[0]
+        if pix:
+            rgba_d = torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
+            cam = np.eye(4, dtype=np.float32)
+        pending = [None] * NB
+
+        def trace_into(b):
+            if pix:   # the full trace step (identity camera) writes the RGBA32F pixel; packed to 8-bit BGRA for the wire
+                scene.trace_pass(rays_d.data_ptr(), None, rgba_d.data_ptr(), n_local, cam, 0, stream)
+                rt.pack_bgra8(local, rgba_d.data_ptr(), n_local, mine[b].data_ptr(), stream)
+            else:
+                scene.intersect_async(rays_d.data_ptr(), n_local, None, mine[b].data_ptr(), stream)
+
+        def start_exchange(b):
+            """Every other rank's records of frame buffer b to rank 0 (point-to-point, grouped: rank 0 receives on its seven
+            xGMI links at once, no ring).  Returns the handles still to be waited for."""
+            if world == 1:
+                return []
+            if rank == 0:
+                ops = [dist.P2POp(dist.irecv, slices[b][r], r) for r in range(1, world)]
+            else:
+                ops = [dist.P2POp(dist.isend, mine[b], 0)]
+            if a.backend == "nccl":
+                return dist.batch_isend_irecv(ops)
+            for q in [op.op(op.tensor, op.peer) for op in ops]:
+                q.wait()
+            return []
+
+        def finish_exchange(b):
+            """Waits (on the stream, not the host) for frame buffer b's records, then scatters them into the framebuffer."""
+            for q in pending[b] or []:
+                q.wait()
+            pending[b] = None
+            if rank == 0:
+                rt.scatter_tiles(local, gather_d[b].data_ptr(), W * H, ids_d.data_ptr(), first_d.data_ptr(), len(ids_h), a.tile, W, H, rec_b,
+                                 fb_d.data_ptr(), stream)
 
         def exchange():
-            """One exchange step: every other rank's compact records to rank 0 (point-to-point, grouped: rank 0
-            receives on its seven xGMI links at once, no ring), then the device scatter into the framebuffer."""
-            if world > 1:
-                if rank == 0:
-                    ops = [dist.P2POp(dist.irecv, slices[r], r) for r in range(1, world)]
-                else:
-                    ops = [dist.P2POp(dist.isend, hits_d, 0)]
-                if a.backend == "nccl":
-                    for q in dist.batch_isend_irecv(ops):
-                        q.wait()
-                else:
-                    for q in [op.op(op.tensor, op.peer) for op in ops]:
-                        q.wait()
-            if rank == 0:
-                rt.scatter_tiles(local, gather_d.data_ptr(), W * H, ids_d.data_ptr(), first_d.data_ptr(), len(ids_h), a.tile, W, H, 16,
-                                 fb_d.data_ptr(), stream)
+            pending[0] = start_exchange(0)
+            finish_exchange(0)
+
+        frame_no = [0]
+
+        def step_sharded():
+            b = frame_no[0] % NB
+            frame_no[0] += 1
+            trace_into(b)
+            if a.pipeline:
+                if pending[1 - b] is not None:
+                    finish_exchange(1 - b)       # the frame before: its records arrived while this one was traced
+                pending[b] = start_exchange(b)
+            else:
+                pending[b] = start_exchange(b)
+                finish_exchange(b)
+
+        def flush():
+            for b in range(NB):
+                if pending[b] is not None:
+                    finish_exchange(b)
 
     def step():
         k = step_no[0] % frames
@@ -275,8 +334,7 @@ def main():
                 scene.trace_pass(src.data_ptr(), dst.data_ptr(), rgba_d.data_ptr(), n_local, cam, 1, stream)
                 src, dst = dst, src
         elif sharded:
-            scene.intersect_async(rays_d.data_ptr(), n_local, None, hits_d.data_ptr(), stream)
-            exchange()
+            step_sharded()
         elif a.raygen == "device" and W:
             scene.trace_primary(W, H, origins[k], hits_d.data_ptr() if full_out else None,
                                 None if full_out else hits_d.data_ptr(), stream)
@@ -287,7 +345,9 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    wall, dev_ms = timed(dist, a.steps, step)
+    if sharded:
+        flush()
+    wall, dev_ms = timed(dist, a.steps, step, flush if sharded else None)
     dev_ms /= passes
     if dist:
         tt = torch.tensor([wall], dtype=torch.float64, device=red_dev)
@@ -305,38 +365,51 @@ def main():
     if sharded:
         # the parts of the step on their own: trace only (slowest rank), exchange only
         sub = max(5, a.steps // 4)
-        w_tr, _ = timed(dist, sub, lambda: scene.intersect_async(rays_d.data_ptr(), n_local, None, hits_d.data_ptr(), stream))
+        w_tr, _ = timed(dist, sub, lambda: trace_into(0))
         w_ex, _ = timed(dist, sub, exchange)
         parts = torch.tensor([w_tr / sub * 1e3, w_ex / sub * 1e3], dtype=torch.float64, device=red_dev)
         if dist:
             dist.all_reduce(parts, op=dist.ReduceOp.MAX)
         extra["trace_only_ms"] = round(float(parts[0]), 4)
         extra["gather_and_scatter_ms"] = round(float(parts[1]), 4)
-        extra["gather_bytes_into_rank0"] = int((W * H - counts[0]) * 16)
+        extra["gather_bytes_into_rank0"] = int((W * H - counts[0]) * rec_b)
+        extra["gathered_record"] = "8-bit BGRA pixel (full trace step + rt_pack_bgra8)" if pix else "16 B {id,t,u,v}"
+        extra["frames_in_flight"] = NB if a.pipeline else 1
         if world > 1:
             # the whole frame on ONE GPU of this job (rank 0 alone, the others wait): the strong-scaling reference point
             if rank == 0:
                 full_d = torch.from_numpy(rt.primary_rays(W, H, origin)).cuda()
-                one_out = torch.empty((W * H, 4), dtype=torch.float32, device="cuda")
+                one_out = records(W * H)
+                one_rgba = torch.empty((W * H, 4), dtype=torch.float32, device="cuda") if pix else None
                 scene.set_param("image_width", W)
+
+                def one_gpu_frame():
+                    if pix:
+                        scene.trace_pass(full_d.data_ptr(), None, one_rgba.data_ptr(), W * H, cam, 0, stream)
+                        rt.pack_bgra8(local, one_rgba.data_ptr(), W * H, one_out.data_ptr(), stream)
+                    else:
+                        scene.intersect_async(full_d.data_ptr(), W * H, None, one_out.data_ptr(), stream)
                 for _ in range(5):
-                    scene.intersect_async(full_d.data_ptr(), W * H, None, one_out.data_ptr(), stream)
+                    one_gpu_frame()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(sub):
-                    scene.intersect_async(full_d.data_ptr(), W * H, None, one_out.data_ptr(), stream)
+                    one_gpu_frame()
                 torch.cuda.synchronize()
                 one_ms = (time.perf_counter() - t0) / sub * 1e3
                 extra["one_gpu_same_frame"] = {"ms_per_step": round(one_ms, 4), "value": round(W * H / (one_ms * 1e-3) / 1e6, 1),
                                                "unit": "Mrays/s", "speedup_of_this_job": round(one_ms / ms_per_step, 3)}
                 # the gathered framebuffer must be the single-GPU framebuffer, byte for byte
                 scene.set_param("image_width", a.tile if (a.image_hint and W % a.tile == 0) else 0)
+                fb_d.fill_(-1)                   # every frame of the loop is the same image: only a wiped framebuffer proves this step's scatter
                 step()
+                flush()
                 torch.cuda.synchronize()
                 extra["framebuffer_equals_one_gpu"] = bool(torch.equal(fb_d.view(torch.int32), one_out.view(torch.int32)))
-                del full_d, one_out
+                del full_d, one_out, one_rgba
             else:
                 step()
+                flush()
             dist.barrier()
 
     if rank == 0:
@@ -355,6 +428,10 @@ def main():
         in_b = 0 if (a.raygen == "device" and W and workload not in ("tiles4k", "mirror5")) else 64
         stream_b = in_b + out_b + (16 if workload == "mirror5" else 0)       # compulsory HBM bytes per ray
         trav_b = 0.0 if workload == "mirror5" else n_node * node_b + n_tri * info["tri_bytes"]
+        if sharded:
+            dev_ms = extra["trace_only_ms"]      # the roofline figures are the trace kernel's, not the exchange's
+            if pix:
+                out_b = 16                       # the RGBA32F pixel the trace step writes (packed to 4 bytes by a second kernel)
         secs = dev_ms * 1e-3
         key = f"{workload}/{a.bvh}/w{width}/out{out_b}/{a.raygen}"
         pmc_table, pmc_src = newest_profile_table("pmc_table.json")
@@ -463,6 +540,10 @@ def main():
         step_no[0] = 0
         if not sharded:
             step()                      # leaves frame 0's hits in hits_d for the spot check below
+        elif world == 1:
+            fb_d.fill_(-1)              # wiped first: the spot check below must see THIS step's gather and scatter
+            step()
+            flush()
         torch.cuda.synchronize()
         cpu = None
         if world == 1 and not a.no_cpu_baseline and workload != "mirror5":
@@ -481,8 +562,18 @@ def main():
             oid, ot, _, _ = oracle.closest_hit(mesh.verts, mesh.faces, sample, threads=threads)
             cdt = time.perf_counter() - c0
             # parity spot-check of the same sample against the GPU result of the last step
-            src = fb_d if sharded else hits_d
-            got = src[torch.from_numpy(sel).cuda()].cpu().numpy()
+            if sharded and pix:
+                # the gathered framebuffer holds pixels, not hits: the sample is traced here once more for the check (the
+                # framebuffer itself is compared with the one-GPU frame byte for byte above)
+                sample_d = torch.from_numpy(np.ascontiguousarray(sample)).cuda()
+                src = torch.empty((len(sel), 4), dtype=torch.float32, device="cuda")
+                scene.set_param("image_width", 0)
+                scene.intersect_async(sample_d.data_ptr(), len(sel), None, src.data_ptr(), stream)
+                torch.cuda.synchronize()
+                got = src.cpu().numpy()
+            else:
+                src = fb_d if sharded else hits_d
+                got = src[torch.from_numpy(sel).cuda()].cpu().numpy()
             gid = got[:, 14 if full_out else 0].view(np.uint32)
             gt = got[:, 15 if full_out else 1]
             hit = oid != rt.MISS_ID
@@ -508,12 +599,12 @@ def main():
                        "bvh": {"fixed": "core/CentroidBVH build, centroid index repaired", "reference": "core/CentroidBVH build as written",
                                "sah": "library surface-area build"}[a.bvh],
                        "bvh_width": width, "nodes": info["nodes4" if width == 4 else "nodes2"],
-                       "hit_record": "64B RayIntersection" if out_b == 64 else "16B {id,t,u,v}",
+                       "hit_record": "64B RayIntersection" if out_b == 64 else ("16B RGBA32F pixel -> 4B BGRA" if (sharded and pix) else "16B {id,t,u,v}"),
                        "frames": frames,
                        "rays": "RayIntersection table resident in HBM" if in_b else "generated in the kernel (rt_trace_primary)",
                        "dispatch_order": "costliest work unit first, from the costs measured two launches earlier" if a.feedback
                        else "image centre first",
-                       "parallelism": f"{world} x one process per GPU, " + ("cost-balanced image squares + RCCL gather + device scatter"
+                       "parallelism": f"{world} x one process per GPU, " + ("cost-balanced image squares + RCCL gather (beside the next frame's trace) + device scatter"
                                                                             if sharded else "frame-parallel")},
             "roofline": roofline, "cpu_baseline": cpu, "same_launch_on_sah_tree": other, "two_frames_in_flight": overlapped,
             "host_pointer_call": host_call,

@@ -238,12 +238,18 @@ int rt_scene_unit_costs_primary(const rt_scene *s, int width, int height, const 
  * NDRange of render_client/img_main.cpp:464-478; it renders straight into one GL texture).  src holds records tile by
  * tile: tile i of the list is square number tile_ids[i] (row-major over the image cut into tile x tile squares, edge
  * squares smaller), its records row-major inside the square, starting at record tile_first[i].  Each record
- * (record_bytes, a multiple of 16) is copied to its pixel of the row-major width x height image dst.  src holds
+ * (record_bytes, a multiple of 4: 16-byte hits, 64-byte records, 4-byte pixels) is copied to its pixel of the row-major width x height image dst.  src holds
  * src_records records; a list entry that names no square of the image, or whose records would run past the end of
  * src, is skipped.  All pointers are device memory of `device`; enqueued on `stream`. */
 int rt_scatter_tiles(int device, const void *src_dev, size_t src_records, const uint32_t *tile_ids_dev,
                      const uint32_t *tile_first_dev, size_t ntiles, int tile, int width, int height, size_t record_bytes,
                      void *dst_dev, void *stream);
+
+/* RGBA32F pixels (what rt_trace_pass writes) -> 8-bit BGRA in the byte order rt_write_bmp32 and the reference's bitmap
+ * writer take (4-byte `pixel`s written as they are, cpu_raycast/bmp.h:12, bmp.c:49-53; a 32-bit BMP stores B, G, R, A):
+ * channel = min(255, max(0, x * 255 + 0.5)) truncated, alpha 255.  A quarter of
+ * the bytes when a framebuffer has to cross GPUs.  Device pointers of `device`, enqueued on `stream`. */
+int rt_pack_bgra8(int device, const float *rgba_dev, size_t n, void *bgra_dev, void *stream);
 
 /* Diagnostic: runs the instrumented kernel once over n device-resident rays and returns, per wave of
  * 64 rays (or per 8x8 tile with the image hint), records[4*w..4*w+3] = {start, end in 100 MHz ticks,

@@ -100,6 +100,7 @@ def _load():
         "rt_scene_unit_costs": (i32, [vp, vp, sz, vp, sz, C.POINTER(sz)]),
         "rt_scene_unit_costs_primary": (i32, [vp, i32, i32, C.POINTER(C.c_float), vp, sz, C.POINTER(sz)]),
         "rt_scatter_tiles": (i32, [i32, vp, sz, vp, vp, sz, i32, i32, i32, sz, vp, vp]),
+        "rt_pack_bgra8": (i32, [i32, vp, sz, vp, vp]),
         "rt_scene_wave_timeline": (i32, [vp, vp, sz, vp, sz]),
         "rt_scene_wave_model": (i32, [vp, vp, sz, u32, u32, sz, i32, C.POINTER(u64)]),
         "rt_debug_tri_batch": (i32, [i32, vp, vp, sz, vp, vp, vp]),
@@ -362,6 +363,11 @@ def scatter_tiles(device, src_ptr, src_records, tile_ids_ptr, tile_first_ptr, nt
     """rt_scatter_tiles on raw device addresses (the caller keeps the index arrays alive until the launch has run)."""
     _check(lib.rt_scatter_tiles(device, _ptr(src_ptr), src_records, _ptr(tile_ids_ptr), _ptr(tile_first_ptr), ntiles, tile, width, height,
                                 record_bytes, _ptr(dst_ptr), C.c_void_p(stream) if stream else None))
+
+
+def pack_bgra8(device, rgba_ptr, n, bgra_ptr, stream=0):
+    """rt_pack_bgra8 on raw device addresses: n RGBA32F pixels -> n 8-bit BGRA pixels."""
+    _check(lib.rt_pack_bgra8(device, _ptr(rgba_ptr), n, _ptr(bgra_ptr), C.c_void_p(stream) if stream else None))
 
 
 def debug_tri_batch(tri, ray, device=0):

@@ -1186,7 +1186,7 @@ int rt_scatter_tiles(int device, const void *src_dev, size_t src_records, const 
 {
   if (!src_dev || !tile_ids_dev || !tile_first_dev || !dst_dev) return Fail(RT_ERR_INVALID, "null argument");
   if (tile <= 0 || width <= 0 || height <= 0) return Fail(RT_ERR_INVALID, "bad tile or image size");
-  if (record_bytes == 0 || record_bytes % 16u != 0 || record_bytes > 1024u) return Fail(RT_ERR_INVALID, "record size must be a multiple of 16 bytes");
+  if (record_bytes == 0 || record_bytes % 4u != 0 || record_bytes > 1024u) return Fail(RT_ERR_INVALID, "record size must be a multiple of 4 bytes, at most 1024");
   if (ntiles == 0) return RT_OK;
   const uint64_t tiles_total = static_cast<uint64_t>((width + tile - 1) / tile) * static_cast<uint64_t>((height + tile - 1) / tile);
   if (ntiles > tiles_total) return Fail(RT_ERR_INVALID, "more tiles listed than the image has");
@@ -1196,6 +1196,17 @@ int rt_scatter_tiles(int device, const void *src_dev, size_t src_records, const 
   RT_HIP(rt::LaunchScatterTiles(src_dev, static_cast<uint32_t>(src_records), tile_ids_dev, tile_first_dev, static_cast<uint32_t>(ntiles), static_cast<uint32_t>(tile),
                                 static_cast<uint32_t>(width), static_cast<uint32_t>(height), static_cast<uint32_t>(record_bytes), dst_dev,
                                 static_cast<hipStream_t>(stream)));
+  return RT_OK;
+}
+
+int rt_pack_bgra8(int device, const float *rgba_dev, size_t n, void *bgra_dev, void *stream)
+{
+  if (!rgba_dev || !bgra_dev) return Fail(RT_ERR_INVALID, "null argument");
+  if (n == 0) return RT_OK;
+  if (n > 0xFFFFFFFFull) return Fail(RT_ERR_INVALID, "more pixels than one launch addresses");
+  DeviceGuard guard(device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  RT_HIP(rt::LaunchPackPixels(rgba_dev, static_cast<uint32_t>(n), bgra_dev, static_cast<hipStream_t>(stream)));
   return RT_OK;
 }
 

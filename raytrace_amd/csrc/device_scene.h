@@ -61,9 +61,11 @@ hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode
 // unit_cost must hold 512 * BuildOrderKeysPerThread(nunits) entries; it is zeroed after being read.
 uint32_t BuildOrderKeysPerThread(uint32_t nunits);
 hipError_t LaunchBuildOrder(uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream);
-// dst[pixel] = src[record] for the listed tiles (see ScatterTilesKernel); record_bytes is a multiple of 16.
+// dst[pixel] = src[record] for the listed tiles (see ScatterTilesKernel); record_bytes is a multiple of 4.
 hipError_t LaunchScatterTiles(const void *src, uint32_t src_records, const uint32_t *tile_ids, const uint32_t *tile_first, uint32_t ntiles,
                               uint32_t tile, uint32_t img_w, uint32_t img_h, uint32_t record_bytes, void *dst, hipStream_t stream);
+// bgra[i] = 8-bit BGRA of the RGBA32F pixel rgba[4i..4i+3] (see PackPixelsKernel).
+hipError_t LaunchPackPixels(const float *rgba, uint32_t n, void *bgra, hipStream_t stream);
 hipError_t LaunchTriBatch(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv,
                           hipStream_t stream);
 

@@ -654,11 +654,13 @@ __global__ void __launch_bounds__(512) BuildOrderKernel(uint32_t *unit_cost, uin
 
 // Tile-major records -> row-major framebuffer.  Tile i of the list covers the pixel block of tile_ids[i] in a W x H image
 // cut into `tile`-sized squares (edge tiles are smaller); its records, row-major inside the block, start at record
-// tile_first[i] of `src`.  One workgroup per tile; a record is `quads` 16-byte pieces, consecutive threads move
-// consecutive pieces, so both sides are read and written in runs of a tile row.
-__global__ void __launch_bounds__(256) ScatterTilesKernel(const uint4 *src, uint32_t src_records, const uint32_t *tile_ids,
+// tile_first[i] of `src`.  One workgroup per tile; a record is `pieces` elements of PIECE (16 bytes, or 4 bytes for records
+// that are not a multiple of 16 such as 8-bit pixels), consecutive threads move consecutive pieces, so both sides are read
+// and written in runs of a tile row.
+template <typename PIECE>
+__global__ void __launch_bounds__(256) ScatterTilesKernel(const PIECE *src, uint32_t src_records, const uint32_t *tile_ids,
                                                           const uint32_t *tile_first, uint32_t tile, uint32_t img_w, uint32_t img_h,
-                                                          uint32_t quads, uint4 *dst)
+                                                          uint32_t pieces, PIECE *dst)
 {
   const uint32_t tiles_x = (img_w + tile - 1u) / tile, tiles_y = (img_h + tile - 1u) / tile;
   const uint32_t id = tile_ids[blockIdx.x];
@@ -667,12 +669,26 @@ __global__ void __launch_bounds__(256) ScatterTilesKernel(const uint4 *src, uint
   const uint32_t x0 = tx * tile, y0 = ty * tile;
   const uint32_t w = min(tile, img_w - x0), h = min(tile, img_h - y0);
   if (static_cast<uint64_t>(tile_first[blockIdx.x]) + static_cast<uint64_t>(w) * h > src_records) return;   // nor one that runs off src
-  const uint32_t row_pieces = w * quads, pieces = row_pieces * h;
-  const uint4 *from = src + static_cast<size_t>(tile_first[blockIdx.x]) * quads;
-  for (uint32_t k = threadIdx.x; k < pieces; k += blockDim.x) {
+  const uint32_t row_pieces = w * pieces, total = row_pieces * h;
+  const PIECE *from = src + static_cast<size_t>(tile_first[blockIdx.x]) * pieces;
+  for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) {
     const uint32_t row = k / row_pieces, col = k - row * row_pieces;
-    dst[(static_cast<size_t>(y0 + row) * img_w + x0) * quads + col] = from[k];
+    dst[(static_cast<size_t>(y0 + row) * img_w + x0) * pieces + col] = from[k];
   }
+}
+
+// RGBA32F pixels -> 8-bit BGRA, the byte order a 32-bit bitmap stores and the reference's writer passes through
+// (cpu_raycast/bmp.h:12, bmp.c:49-53): each channel
+// min(255, max(0, x * 255 + 0.5)) truncated, alpha 255.
+__global__ void __launch_bounds__(256) PackPixelsKernel(const float4 *rgba, uint32_t n, uint32_t *bgra)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 c = rgba[i];
+  const uint32_t r = static_cast<uint32_t>(fminf(255.f, fmaxf(0.f, c.x * 255.f + 0.5f)));
+  const uint32_t g = static_cast<uint32_t>(fminf(255.f, fmaxf(0.f, c.y * 255.f + 0.5f)));
+  const uint32_t b = static_cast<uint32_t>(fminf(255.f, fmaxf(0.f, c.z * 255.f + 0.5f)));
+  bgra[i] = b | (g << 8) | (r << 16) | 0xFF000000u;
 }
 
 __global__ void TriBatchKernel(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv)
@@ -740,8 +756,20 @@ hipError_t LaunchScatterTiles(const void *src, uint32_t src_records, const uint3
                               uint32_t tile, uint32_t img_w, uint32_t img_h, uint32_t record_bytes, void *dst, hipStream_t stream)
 {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(ScatterTilesKernel, dim3(ntiles), dim3(256), 0, stream, static_cast<const uint4 *>(src), src_records, tile_ids, tile_first, tile,
-                     img_w, img_h, record_bytes / 16u, static_cast<uint4 *>(dst));
+  if (record_bytes % 16u == 0u)
+    hipLaunchKernelGGL(ScatterTilesKernel<uint4>, dim3(ntiles), dim3(256), 0, stream, static_cast<const uint4 *>(src), src_records, tile_ids,
+                       tile_first, tile, img_w, img_h, record_bytes / 16u, static_cast<uint4 *>(dst));
+  else
+    hipLaunchKernelGGL(ScatterTilesKernel<uint32_t>, dim3(ntiles), dim3(256), 0, stream, static_cast<const uint32_t *>(src), src_records, tile_ids,
+                       tile_first, tile, img_w, img_h, record_bytes / 4u, static_cast<uint32_t *>(dst));
+  return hipGetLastError();
+}
+
+hipError_t LaunchPackPixels(const float *rgba, uint32_t n, void *bgra, hipStream_t stream)
+{
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(PackPixelsKernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, reinterpret_cast<const float4 *>(rgba), n,
+                     static_cast<uint32_t *>(bgra));
   return hipGetLastError();
 }
 

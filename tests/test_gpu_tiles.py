@@ -84,3 +84,44 @@ def test_sharded_render_equals_single_launch(rt, gpu, shape):
         assert torch.equal(fb64.view(torch.int32), before.view(torch.int32))
     finally:
         scene.close()
+
+
+def test_pixels_pack_to_bgra_and_scatter_as_4_byte_records(rt, gpu):
+    """The full trace step's RGBA32F pixels packed to 8-bit BGRA (rt_pack_bgra8), stacked square by square and scattered
+    back with 4-byte records: the framebuffer a multi-GPU render gathers when it ships pixels instead of hits."""
+    import torch
+    from raytrace_amd.tiles import assign_tiles, rays_of_tiles, tile_grid
+    W, H, tile = 328, 200, 32
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "cube_mirror_test.obj"), "reference")     # the one model that ships materials
+    bvh = rt.BVH(mesh, "fixed")
+    rays = rt.primary_rays(W, H, rt.frame_camera(bvh.root_box, W, H))
+    scene = rt.Scene(mesh, bvh, device=gpu, width=4)
+    try:
+        scene.set_param("image_width", W)
+        rays_d = torch.from_numpy(rays).cuda()
+        rgba = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
+        scene.trace_pass(rays_d.data_ptr(), None, rgba.data_ptr(), W * H, np.eye(4, dtype=np.float32), 0)
+        pixels = torch.zeros((W * H, 1), dtype=torch.int32, device="cuda")
+        rt.pack_bgra8(gpu, rgba.data_ptr(), W * H, pixels.data_ptr())
+        torch.cuda.synchronize()
+        c = rgba.cpu().numpy()
+        q = np.minimum(np.float32(255), np.maximum(np.float32(0), c * np.float32(255) + np.float32(0.5))).astype(np.uint32)
+        want_px = (q[:, 2] | (q[:, 1] << 8) | (q[:, 0] << 16) | np.uint32(0xFF000000)).astype(np.uint32)
+        assert np.array_equal(pixels.cpu().numpy().view(np.uint32).reshape(-1), want_px)
+        assert len(np.unique(want_px)) > 2       # background, and faces shaded by their angle to the ray
+        tx, ty = tile_grid(W, H, tile)
+        for G in (1, 3):
+            lists = assign_tiles(tx * ty, G, None)
+            order = np.concatenate(lists)
+            idx, first = rays_of_tiles(W, H, tile, order)
+            stacked = pixels[torch.from_numpy(idx).cuda()].contiguous()
+            ids_d = torch.from_numpy(order.astype(np.int32)).cuda()
+            first_d = torch.from_numpy(first.astype(np.int32)).cuda()
+            fb = torch.zeros_like(pixels)
+            rt.scatter_tiles(gpu, stacked.data_ptr(), W * H, ids_d.data_ptr(), first_d.data_ptr(), len(order), tile, W, H, 4, fb.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(fb, pixels), G
+        with pytest.raises(rt.RtError):
+            rt.scatter_tiles(gpu, stacked.data_ptr(), W * H, ids_d.data_ptr(), first_d.data_ptr(), len(order), tile, W, H, 6, fb.data_ptr())
+    finally:
+        scene.close()

@@ -10,5 +10,6 @@ for line in sys.stdin:
         continue
     d = json.loads(line)
     r = d["roofline"]
-    print(f"{tag:40s} {d['value']:9.1f} Mrays/s  kernel {r['kernel_ms']:.4f} ms  frac {r['frac']:.3f}  "
-          f"nodes/ray {r['node_records_per_ray']:.2f} tris/ray {r['tri_records_per_ray']:.2f}  B/ray {r['bytes_per_ray']:.0f}", flush=True)
+    g = r["algorithmic"]
+    print(f"{tag:40s} {d['value']:9.1f} Mrays/s  step {d['ms_per_step']:.4f} ms  kernel {r['kernel_ms']:.4f} ms  {r['bound']} frac {r['frac']:.3f}  "
+          f"nodes/ray {g['node_records_per_ray']:.2f} tris/ray {g['tri_records_per_ray']:.2f}  B/ray {g['bytes_per_ray']:.0f}", flush=True)
