@@ -581,6 +581,31 @@ def main():
                    "sample": what, "seconds": round(cdt, 2), "id_mismatches_vs_gpu": int((gid != oid).sum()),
                    "t_bit_mismatches_vs_gpu": int((gt[hit].view(np.uint32) != ot[hit].view(np.uint32)).sum())}
 
+        # The accelerated CPU figure: the oracle's walk of the same CentroidBVH tree over EVERY ray of the step (the first 4 Mi of the
+        # AO set), and with it a comparison of every hit of the last step with the CPU's.
+        cpu_bvh = None
+        if world == 1 and not a.no_cpu_baseline and workload != "mirror5":
+            import oracle
+            all_rays = rays_h if not sharded else rt.primary_rays(W, H, origin)
+            threads = oracle.default_threads()
+            c0 = time.perf_counter()
+            oid, ot, _, _ = oracle.closest_hit_bvh(mesh.verts, mesh.faces, bvh.nodes, all_rays, threads=threads)
+            cdt = time.perf_counter() - c0
+            hit = oid != rt.MISS_ID
+            if sharded and pix:      # the framebuffer holds pixels: nothing to hold against the CPU's hits
+                gid, gt = oid, ot
+            else:
+                src = fb_d if sharded else hits_d
+                got = src[:len(all_rays)].cpu().numpy()
+                gid = got[:, 14 if full_out else 0].view(np.uint32)
+                gt = got[:, 15 if full_out else 1]
+            cpu_bvh = {"value": round(len(all_rays) / cdt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                       "sample": f"all {len(all_rays)} rays" + (f" of the first slice of the {n_local}" if len(all_rays) != n_local else "") +
+                                 ", closest hit through the same CentroidBVH tree (oracle tree walk)",
+                       "seconds": round(cdt, 2), "id_mismatches_vs_gpu": int((gid != oid).sum()),
+                       "t_bit_mismatches_vs_gpu": int((gt[hit].view(np.uint32) != ot[hit].view(np.uint32)).sum())}
+            del all_rays
+
         if workload == "mirror5":
             what = f"{model} {W}x{H} primary pass + 4 reflection passes (full trace kernel)"
         elif sharded:
@@ -606,7 +631,7 @@ def main():
                        else "image centre first",
                        "parallelism": f"{world} x one process per GPU, " + ("cost-balanced image squares + RCCL gather (beside the next frame's trace) + device scatter"
                                                                             if sharded else "frame-parallel")},
-            "roofline": roofline, "cpu_baseline": cpu, "same_launch_on_sah_tree": other, "two_frames_in_flight": overlapped,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_bvh": cpu_bvh, "same_launch_on_sah_tree": other, "two_frames_in_flight": overlapped,
             "host_pointer_call": host_call,
         }
         line.update(extra)

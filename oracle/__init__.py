@@ -29,6 +29,8 @@ def _load_oracle():
     lib = C.CDLL(ORACLE_PATH)
     lib.oracle_closest_hit.restype = _i32
     lib.oracle_closest_hit.argtypes = [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _i32]
+    lib.oracle_closest_hit_bvh.restype = _i32
+    lib.oracle_closest_hit_bvh.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _i32]
     lib.oracle_tri_batch.restype = None
     lib.oracle_tri_batch.argtypes = [_vp, _vp, _sz, _vp, _vp, _vp]
     lib.oracle_aabb_batch.restype = None
@@ -97,6 +99,21 @@ def closest_hit(verts, faces, rays, threads=None, want_second=False):
         raise RuntimeError("oracle_closest_hit failed")
     out = (hits[:, 0].view(np.uint32).copy(), hits[:, 1].copy(), hits[:, 2].copy(), hits[:, 3].copy())
     return out + (second,) if want_second else out
+
+
+def closest_hit_bvh(verts, faces, nodes, rays, threads=None):
+    """The same closest hit through the reference-format tree `nodes` ((n, 20) u32 = 80-byte CentroidBVHNode records):
+    returns (ids u32, t f32, u f32, v f32), equal to closest_hit()'s."""
+    verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 4)
+    faces = np.ascontiguousarray(faces, np.uint32).reshape(-1, 8)
+    nodes = np.ascontiguousarray(nodes, np.uint32).reshape(-1, 20)
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 16)
+    n = len(rays)
+    hits = np.zeros((n, 4), np.float32)
+    rc = lib.oracle_closest_hit_bvh(_p(verts), _p(faces), _p(nodes), len(nodes), _p(rays), n, _p(hits), threads or default_threads())
+    if rc != 0:
+        raise RuntimeError("oracle_closest_hit_bvh failed (malformed or too deep a tree)")
+    return hits[:, 0].view(np.uint32).copy(), hits[:, 1].copy(), hits[:, 2].copy(), hits[:, 3].copy()
 
 
 def _batch(fn, tri, ray):

@@ -194,6 +194,108 @@ int oracle_closest_hit(const rt_vec3 *verts, const rt_face *faces, size_t ntris,
   return 0;
 }
 
+/* The same closest hit found through the reference's own tree (core/CentroidBVH.h:52-59 nodes, root at 0): a plain
+ * stack walk, children tested with a slab test whose box is pushed outward by 2^-17 of (largest |origin| + largest
+ * |box coordinate|) so that rounding can never cull a box that holds an accepted hit, boxes entered when their entry
+ * distance is <= the best hit so far (inclusive), and on equal t the lower triangle index kept: the answer does not
+ * depend on the order of the walk and equals the brute-force loop's, which tests/test_oracle.py asserts.  The
+ * reference has no CPU traversal (its cpu_raycast is the brute-force loop); this is the "accelerated CPU" figure
+ * beside it, timed by bench.py, and a second opinion on the kernels' answers that shares no traversal code with them. */
+typedef struct {
+  const rt_vec3 *verts; const rt_face *faces; const rt_bvh_node *nodes; size_t nnodes;
+  const rt_ray_isect *rays; size_t begin, end;
+  rt_hit16 *hits; int failed;
+} bvh_job;
+
+static int padded_slab(const rt_aabb *bb, const float o[3], const float inv[3], float pad, float closest, float *tenter)
+{
+  const float *lo = &bb->a.x, *hi = &bb->b.x;
+  float tmin = 0.f, tmax = closest;
+  for (int i = 0; i < 3; ++i) {
+    float t1 = ((lo[i] - pad) - o[i]) * inv[i], t2 = ((hi[i] + pad) - o[i]) * inv[i];
+    if (t1 != t1 || t2 != t2) continue;   /* 0 * inf: the origin lies on a padded plane of a flat direction: no constraint */
+    float a = t1 < t2 ? t1 : t2, b = t1 < t2 ? t2 : t1;
+    a -= fabsf(a) * 1e-6f; b += fabsf(b) * 1e-6f;   /* the two roundings of each product */
+    if (a > tmin) tmin = a;
+    if (b < tmax) tmax = b;
+  }
+  *tenter = tmin;
+  return tmin <= tmax;
+}
+
+static void *bvh_worker(void *arg)
+{
+  bvh_job *j = (bvh_job *)arg;
+  uint32_t stack[256];
+  float scale = 0.f;
+  const float *rb = &j->nodes[0].aabb.a.x;
+  for (int i = 0; i < 8; ++i) if (i != 3 && i != 7 && fabsf(rb[i]) > scale) scale = fabsf(rb[i]);
+  for (size_t k = j->begin; k < j->end; ++k) {
+    rt_ray ray;
+    ray.origin.x = j->rays[k].origin.x; ray.origin.y = j->rays[k].origin.y; ray.origin.z = j->rays[k].origin.z; ray.origin.w = 0.f;
+    ray.dir.x = j->rays[k].direction.x; ray.dir.y = j->rays[k].direction.y; ray.dir.z = j->rays[k].direction.z; ray.dir.w = 0.f;
+    const float o[3] = { ray.origin.x, ray.origin.y, ray.origin.z };
+    const float inv[3] = { 1.f / ray.dir.x, 1.f / ray.dir.y, 1.f / ray.dir.z };
+    float omax = fabsf(o[0]) > fabsf(o[1]) ? fabsf(o[0]) : fabsf(o[1]);
+    if (fabsf(o[2]) > omax) omax = fabsf(o[2]);
+    const float pad = 7.62939453125e-06f * (omax + scale);
+    float closest = 3.402823466e+38f;
+    rt_hit16 h = { RT_MISS_ID, closest, 0.f, 0.f };
+    int sp = 0;
+    float te;
+    if (padded_slab(&j->nodes[0].aabb, o, inv, pad, closest, &te)) stack[sp++] = 0;
+    while (sp) {
+      const rt_bvh_node *n = &j->nodes[stack[--sp]];
+      if (n->type == RT_BVH_LEAF) {
+        for (uint32_t q = 0; q < n->node.leaf.count && q < RT_TRIS_PER_LEAF; ++q) {
+          const uint32_t mi = n->node.leaf.tris[q];
+          const uint32_t *s = j->faces[mi].s;
+          rt_vec2 uv; float dist;
+          if (oracle_intersect_ray_triangle(&j->verts[s[0]], &j->verts[s[1]], &j->verts[s[2]], &ray, &uv, &dist) &&
+              (dist < closest || (dist == closest && mi < h.triangle_id))) {
+            closest = dist; h.triangle_id = mi; h.t = dist; h.u = uv.u; h.v = uv.v;
+          }
+        }
+        continue;
+      }
+      const uint32_t c0 = n->node.inner.children_index[0], c1 = n->node.inner.children_index[1];
+      if (c0 >= j->nnodes || c1 >= j->nnodes || sp + 2 > 256) { j->failed = 1; break; }
+      float t0, t1;
+      const int h0 = padded_slab(&j->nodes[c0].aabb, o, inv, pad, closest, &t0);
+      const int h1 = padded_slab(&j->nodes[c1].aabb, o, inv, pad, closest, &t1);
+      if (h0 && h1) {   /* nearer child on top */
+        if (t1 < t0) { stack[sp++] = c0; stack[sp++] = c1; } else { stack[sp++] = c1; stack[sp++] = c0; }
+      } else if (h0) stack[sp++] = c0;
+      else if (h1) stack[sp++] = c1;
+    }
+    j->hits[k] = h;
+  }
+  return NULL;
+}
+
+/* hits[k] = closest hit of rays[k] through the tree `nodes`; returns 0, or -1 if the tree is malformed or deeper than
+ * the walk's 256-entry stack.  nthreads <= 0 -> 1. */
+int oracle_closest_hit_bvh(const rt_vec3 *verts, const rt_face *faces, const rt_bvh_node *nodes, size_t nnodes,
+                           const rt_ray_isect *rays, size_t nrays, rt_hit16 *hits, int nthreads)
+{
+  if (nnodes == 0) return -1;
+  if (nthreads <= 0) nthreads = 1;
+  if ((size_t)nthreads > nrays) nthreads = nrays ? (int)nrays : 1;
+  pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+  bvh_job *jobs = (bvh_job *)malloc(sizeof(bvh_job) * nthreads);
+  if (!th || !jobs) { free(th); free(jobs); return -1; }
+  for (int i = 0; i < nthreads; ++i) {
+    bvh_job jb = { verts, faces, nodes, nnodes, rays, nrays * i / nthreads, nrays * (i + 1) / nthreads, hits, 0 };
+    jobs[i] = jb;
+    if (i > 0) pthread_create(&th[i], NULL, bvh_worker, &jobs[i]);
+  }
+  bvh_worker(&jobs[0]);
+  int failed = jobs[0].failed;
+  for (int i = 1; i < nthreads; ++i) { pthread_join(th[i], NULL); failed |= jobs[i].failed; }
+  free(th); free(jobs);
+  return failed ? -1 : 0;
+}
+
 /* Batch form of the single test, for the bit-equality sweeps:
  * tri[i] = 3 x rt_vec3, ray[i]; out_hit[i], out_t[i], out_uv[i]. */
 void oracle_tri_batch(const rt_vec3 *tri, const rt_ray *ray, size_t n, int32_t *out_hit, float *out_t, rt_vec2 *out_uv)

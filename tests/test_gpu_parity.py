@@ -169,6 +169,27 @@ def test_incoherent_rays_at_the_full_64_mi(rt, oracle, gpu):
         scene.close()
 
 
+def test_every_ray_of_the_full_size_frames_matches_the_oracle(rt, oracle, gpu):
+    """All 2 073 600 rays of the 1080p dragon frame, all 2 073 600 of the bunny frame and all 8 294 400 of the 4K dragon
+    frame against the oracle's tree walk (which equals its brute-force loop bit for bit, tests/test_oracle.py): ids and the
+    bits of t, u, v."""
+    for model, W, H in (("dragon.obj", 1920, 1080), ("bunny.obj", 1920, 1080), ("dragon.obj", 3840, 2160)):
+        mesh = rt.Mesh.load_obj(os.path.join(MODELS, model), "tolerant")
+        bvh = rt.BVH(mesh, "fixed")
+        rays = framed_primary(rt, bvh, W, H)
+        s = rt.Scene(mesh, bvh, device=gpu, width=4)
+        s.set_param("image_width", W)
+        s.set_param("feedback", 1)
+        hits = s.intersect(rays)
+        s.close()
+        ids, t, u, v = rt.hit_fields(hits)
+        oid, ot, ou, ov = oracle.closest_hit_bvh(mesh.verts, mesh.faces, bvh.nodes, rays)
+        h = oid != rt.MISS_ID
+        assert h.sum() > 0.2 * len(rays)
+        assert np.array_equal(ids, oid)
+        assert np.array_equal(bits(t[h]), bits(ot[h])) and np.array_equal(bits(u[h]), bits(ou[h])) and np.array_equal(bits(v[h]), bits(ov[h]))
+
+
 def test_full_size_properties(rt, gpu):
     """Full benchmark sizes, checked through size-independent properties: the record layouts and both
     ray-to-lane mappings agree on every one of the 2 073 600 / 8 294 400 rays, hit records are

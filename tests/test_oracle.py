@@ -1,10 +1,12 @@
 """The CPU oracle: known-answer tests from the reference (cpu_raycast/raycast.cpp:8-21 `main0`)
 and bit-equality with the reference's own core/ray_tri.cpp / core/raymath.cpp where
 oracle/_ref has been built (it is built wherever /root/reference exists)."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import bits
+from conftest import MODELS, bits
 
 
 def _ray(o, d):
@@ -120,6 +122,36 @@ def test_oracle_aabb_and_normalize_match_reference(oracle):
         out = np.zeros(4, np.float32)
         r.ref_normalize(C.c_void_p(v.ctypes.data), C.c_void_p(out.ctypes.data))
         assert np.array_equal(bits(tab[i + j * W, 4:7]), bits(out[:3]))
+
+
+def test_tree_walk_returns_the_brute_force_answer_bit_for_bit(rt, oracle):
+    """The oracle's closest hit through the reference-format tree (every builder, coherent and incoherent rays, and the
+    coplanar tie) equals its brute-force loop in ids and in the bits of t, u, v: the accelerated CPU figure of the
+    benchmark and the full-size GPU parity tests lean on it."""
+    for model, W, H in (("dragon.obj", 96, 54), ("teapot.obj", 128, 72), ("cube.obj", 48, 48)):
+        mesh = rt.Mesh.load_obj(os.path.join(MODELS, model), "tolerant")
+        for mode in ("fixed", "sah") + (("reference",) if model != "dragon.obj" else ()):
+            bvh = rt.BVH(mesh, mode)
+            rays = rt.primary_rays(W, H, rt.frame_camera(bvh.root_box, W, H))
+            if model == "teapot.obj":
+                rays = np.concatenate([rays, rt.ao_rays(mesh, bvh.root_box, 3, 0, 4000)])
+            a = oracle.closest_hit(mesh.verts, mesh.faces, rays, threads=8)
+            b = oracle.closest_hit_bvh(mesh.verts, mesh.faces, bvh.nodes, rays, threads=8)
+            assert (a[0] != rt.MISS_ID).sum() > 100
+            for x, y in zip(a, b):
+                assert np.array_equal(bits(x), bits(y)), (model, mode)
+    # the coplanar pair of the tie test below, through a hand-made two-leaf tree
+    verts = np.array([[0, 0, 0, 1], [1, 0, 0, 1], [1, 1, 0, 1], [0, 1, 0, 1]], np.float32)
+    faces = np.zeros((2, 8), np.uint32)
+    faces[0, :3] = (0, 1, 2)
+    faces[1, :3] = (0, 2, 3)
+    mesh = rt.Mesh.from_arrays(verts, faces)
+    bvh = rt.BVH(mesh, "fixed")
+    rays = np.zeros((2, 16), np.float32)
+    rays[:, 0:3] = [(0.5, 0.5, -1), (0.25, 0.75, -1)]
+    rays[:, 6] = 1
+    ids, t, _, _ = oracle.closest_hit_bvh(verts, faces, bvh.nodes, rays, threads=1)
+    assert ids.tolist() == [0, 1] and t.tolist() == [1.0, 1.0]
 
 
 def test_brute_force_tie_goes_to_lowest_index_and_second_t(oracle):
