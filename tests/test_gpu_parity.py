@@ -123,27 +123,34 @@ def test_incoherent_rays_match_oracle(rt, oracle, gpu):
 
 def test_incoherent_rays_at_the_full_64_mi(rt, oracle, gpu):
     """The divergence-stress configuration at its stated size: 64 Mi seeded AO-style rays through bunny_big in one
-    call (4.3 GB of ray records resident in HBM, 1 GB of compact hits).  Checked through what does not need the
-    oracle on every ray -- ids in range, a plausible hit share, the same bits from a second launch and from the
-    two-wide layout on a 4 Mi slice -- and against the brute-force oracle on a sub-sample spread over the whole set."""
+    call (4.3 GB of ray records resident in HBM, 1 GB of compact hits).  Every one of the 67 108 864 hits is compared
+    (ids and the bits of t, u, v) with the oracle's tree walk, slice by slice; a sub-sample spread over the whole set is
+    also held against the brute-force loop, and a second launch and the two-wide layout must return the same bits."""
     import torch
     mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny_big.obj"), "tolerant")
     bvh = rt.BVH(mesh, "fixed")
     n, piece = 64 << 20, 4 << 20
     rays_d = torch.empty((n, 16), dtype=torch.float32, device="cuda")
     step = 16411                                     # sub-sample stride (prime), 4089 rays
-    sample = []
+    sample, walked = [], []
     for off in range(0, n, piece):                   # generated and uploaded in slices: no 4.3 GB host table
         part = rt.ao_rays(mesh, bvh.root_box, 1234, off, piece)
         first = (-off) % step
         sample.append(part[first::step].copy())
         rays_d[off:off + piece].copy_(torch.from_numpy(part))
+        walked.append(np.stack([x.view(np.uint32) for x in oracle.closest_hit_bvh(mesh.verts, mesh.faces, bvh.nodes, part)], axis=1))
     sample = np.concatenate(sample)
     scene = rt.Scene(mesh, bvh, device=gpu, width=4)
     try:
         hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
         scene.intersect_async(rays_d.data_ptr(), n, None, hits.data_ptr())
         torch.cuda.synchronize()
+        for k, want in enumerate(walked):            # every ray: ids everywhere, t/u/v where there is a hit
+            got = hits[k * piece:(k + 1) * piece].cpu().numpy().view(np.uint32)
+            assert np.array_equal(got[:, 0], want[:, 0]), k
+            hk = want[:, 0] != rt.MISS_ID
+            assert np.array_equal(got[hk], want[hk]), k
+        del walked
         ids = hits[:, 0].view(torch.int32)
         hit = ids != -1
         assert bool(((ids >= 0) & (ids < len(mesh.faces)) | ~hit).all())
