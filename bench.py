@@ -411,6 +411,27 @@ def main():
                 step()
                 flush()
             dist.barrier()
+            # weak scaling beside it: every rank traces its own 1920x1080 dragon frame (64-byte records), no exchange
+            Wf, Hf = 1920, 1080
+            of = rt.frame_camera(box, Wf, Hf)
+            of[0] += rank * 0.01 * float(box[1, 0] - box[0, 0])
+            rays_f = torch.from_numpy(rt.primary_rays(Wf, Hf, of)).cuda()
+            hits_f = torch.empty((Wf * Hf, 16), dtype=torch.float32, device="cuda")
+            scene.set_param("image_width", Wf)
+
+            def step_f():
+                scene.intersect_async(rays_f.data_ptr(), Wf * Hf, hits_f.data_ptr(), None, stream)
+            for _ in range(a.warmup):
+                step_f()
+            w_f, _ = timed(dist, a.steps, step_f)
+            tf = torch.tensor([w_f], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            ms_f = float(tf.item()) * 1e3 / max(1, a.steps)
+            extra["frame_parallel_weak_scaling"] = {"workload": "dragon.obj 1920x1080 primary rays, one frame per rank, no exchange",
+                                                    "ms_per_step": round(ms_f, 4), "value": round(world * Wf * Hf / (ms_f * 1e-3) / 1e6, 1),
+                                                    "unit": "Mrays/s", "scaling": "weak"}
+            scene.set_param("image_width", a.tile if (a.image_hint and W % a.tile == 0) else 0)
+            del rays_f, hits_f
 
     if rank == 0:
         # ---- algorithmic bytes per ray: records the traversal fetches, counted exactly by the instrumented kernel ----
