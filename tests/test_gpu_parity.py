@@ -197,6 +197,30 @@ def test_every_ray_of_the_full_size_frames_matches_the_oracle(rt, oracle, gpu):
         assert np.array_equal(bits(t[h]), bits(ot[h])) and np.array_equal(bits(u[h]), bits(ou[h])) and np.array_equal(bits(v[h]), bits(ov[h]))
 
 
+@pytest.mark.parametrize("model,loader", [("teapot.obj", "reference"), ("sphere.obj", "tolerant"), ("wheel.obj", "tolerant"),
+                                          ("cube_mirror_test.obj", "reference"), ("bunny_big.obj", "tolerant"),
+                                          ("std_square.obj", "tolerant"), ("tri.obj", "tolerant")])
+def test_every_model_every_layout_every_ray(rt, oracle, gpu, model, loader):
+    """Each shipped mesh, each tree (centroid and surface-area), each record layout (two- / four-wide, quantized / float boxes),
+    a 1280x720 frame with and without the image hint: all 921 600 hits against the oracle's tree walk, bit for bit."""
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, model), loader)
+    W, H = 1280, 720
+    for mode in ("fixed", "sah"):
+        bvh = rt.BVH(mesh, mode)
+        rays = framed_primary(rt, bvh, W, H)
+        want = np.stack([x.view(np.uint32) for x in oracle.closest_hit_bvh(mesh.verts, mesh.faces, bvh.nodes, rays)], axis=1)
+        h = want[:, 0] != rt.MISS_ID
+        assert h.sum() > 1000, (model, mode)
+        for width, quant, hint in ((4, 1, W), (2, 1, W), (4, 0, 0), (2, 0, W), (4, 1, 0)):
+            s = rt.Scene(mesh, bvh, device=gpu, width=width)
+            s.set_param("quantized", quant)
+            s.set_param("image_width", hint)
+            got = np.stack([x.view(np.uint32) for x in rt.hit_fields(s.intersect(rays))], axis=1)
+            s.close()
+            assert np.array_equal(got[:, 0], want[:, 0]), (model, mode, width, quant, hint)
+            assert np.array_equal(got[h], want[h]), (model, mode, width, quant, hint)
+
+
 def test_full_size_properties(rt, gpu):
     """Full benchmark sizes, checked through size-independent properties: the record layouts and both
     ray-to-lane mappings agree on every one of the 2 073 600 / 8 294 400 rays, hit records are
