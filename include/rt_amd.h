@@ -136,6 +136,10 @@ int rt_scene_records(const rt_scene *s, int which, void *out, size_t capacity, s
  *                    by share/128, for the units within `radius` of it (tiles in both image directions), so
  *                    that the order still starts the right tiles first when the camera moved between the
  *                    launches.  Defaults 1 and 96; 0 and anything = exact per-unit costs, best for repeated rays.
+ *   "split_units"    0..65536 (default 32, with "feedback"): a launch ends with its longest wave, and a wave is as
+ *                    long as the traversal steps its rays need between them; this many units at the head of the
+ *                    costliest-first order are traced by four waves each (4x4 pixels or 16 records per wave) instead
+ *                    of one.  Capped at the launch's unit count; 0 = never.
  *   "leaf_pct"       1..100: a wave switches from node steps to leaf steps once this share of its busy lanes
  *                    holds a leaf; 100 = descend until every lane does.
  *   "block_threads"  64 (default), 128 or 256.

@@ -136,6 +136,7 @@ struct rt_scene {
   mutable hipStream_t side = nullptr;                       // the order-building kernel runs here, beside the next trace
   mutable hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_sort[2] = {nullptr, nullptr};
   int waves_per_cu = 0;          // optional resident-wave cap per CU, held through the LDS stack size (0 = none)
+  int split_units = 32;          // with a cost-sorted order: this many units, the costliest, are traced by four waves each
   int prio_permille = 0;         // with a cost-sorted order: this share (1/1000) of the leading dispatch slots runs at raised priority
   int lds_stack = 10;            // traversal-stack entries per lane kept in LDS; deeper entries spill to private memory
   int persistent = 0;            // 1: a fixed grid of waves pulls work units from a global cursor (one atomic per unit)
@@ -284,7 +285,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     const uint32_t min_bytes = 160u * 1024u / (groups + 1u) + 1u, entry_bytes = 8u * block;
     a.stack_entries = std::max(a.stack_entries, (min_bytes + entry_bytes - 1u) / entry_bytes);
   }
-  uint32_t grid = (a.ntasks + wpb - 1u) / wpb;   // one wave per work unit
+  uint32_t grid = (a.ntasks + wpb - 1u) / wpb;   // one wave per work unit (more below if the costliest units are split)
   if (s->persistent && !count) {
     // a fixed number of resident waves; each takes units from a cursor word that this launch's stream zeroes first
     grid = std::min(grid, static_cast<uint32_t>(s->num_cu) * std::max(1u, static_cast<uint32_t>(s->persistent_waves) / wpb));
@@ -315,8 +316,20 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     // side stream next to this launch and is ready for launch k+1.  Set `fb_slot` alternates between the two.
     fb_slot = static_cast<int>(s->fb_launch & 1u);
     if (s->fb_sorted[fb_slot]) {
-      RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[fb_slot], 0));
+      // that sort ran beside the previous launch and has normally finished long ago: only a sort still running puts a
+      // wait (one more packet ahead of the trace kernel) into the stream
+      if (hipEventQuery(s->ev_sort[fb_slot]) != hipSuccess) {
+        (void)hipGetLastError();
+        RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[fb_slot], 0));
+      }
       a.order = s->d_fb_order[fb_slot];
+    }
+    if (a.order && !a.cursor && mode != rt::kModeTrace) {
+      // The launch cannot end before its longest wave does, and a wave's length is the number of traversal steps its 64 rays
+      // need between them.  The costliest units are therefore cut into four (16 rays per wave, 4x4 pixels or 16 records):
+      // four shorter waves instead of one long one, for a few percent more waves in total.
+      a.split_units = std::min(static_cast<uint32_t>(s->split_units), a.ntasks);
+      grid = (a.ntasks + 3u * a.split_units + wpb - 1u) / wpb;
     }
     if (a.order) a.prio_slots = static_cast<uint32_t>(static_cast<uint64_t>(a.ntasks) * static_cast<uint32_t>(s->prio_permille) / 1000u);
     a.unit_cost = s->d_fb_cost[fb_slot];
@@ -334,13 +347,14 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     if (rc != RT_OK) return rc;
   }
   {
-    hipError_t e_ = rt::LaunchClosestHit(a, s->width, s->quant != 0, mode, count, grid, block, stream);
+    hipError_t e_ = rt::LaunchClosestHit(a, s->width, s->quant != 0, mode, count, grid, block, stream,
+                                         fb_slot >= 0 ? s->ev_main[fb_slot] : nullptr);
     if (e_ != hipSuccess)
       return Fail(RT_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(e_) + " (grid " + std::to_string(grid) +
                                      ", block " + std::to_string(block) + ", stack entries " + std::to_string(a.stack_entries) + ")");
   }
   if (fb_slot >= 0) {
-    RT_HIP(hipEventRecord(s->ev_main[fb_slot], stream));
+    // ev_main[fb_slot] is signalled by the trace kernel itself (its launch carried the event)
     RT_HIP(hipStreamWaitEvent(s->side, s->ev_main[fb_slot], 0));
     RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_order[fb_slot], s->side));
     RT_HIP(hipEventRecord(s->ev_sort[fb_slot], s->side));
@@ -705,6 +719,9 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "leaf_pct") {
     if (value < 1 || value > 100) return Fail(RT_ERR_INVALID, "leaf_pct must be in 1..100");
     s->leaf_pct = value;
+  } else if (k == "split_units") {
+    if (value < 0 || value > 65536) return Fail(RT_ERR_INVALID, "split_units must be in 0..65536");
+    s->split_units = value;
   } else if (k == "prio_permille") {
     if (value < 0 || value > 1000) return Fail(RT_ERR_INVALID, "prio_permille must be in 0..1000");
     s->prio_permille = value;

@@ -40,6 +40,7 @@ struct KernelArgs {
   unsigned long long *timeline;  // instrumented build only, nullable: per wave {start, end (100 MHz ticks), hw id, xcc id}
   uint32_t n;
   uint32_t ntasks;            // wave-sized work items: ceil(n/64), or the number of 8x8 tiles
+  uint32_t split_units;       // the first this-many units of `order` are traced by four waves each, a quarter of the unit's rays per wave
   uint32_t prio_slots;        // the first this-many dispatch slots run at raised issue priority (0 = none)
   uint32_t cost_radius;       // a unit's cost is also recorded for its neighbours within this many units (<= 3)
   uint32_t cost_share;        // ... scaled by this many 128ths
@@ -49,14 +50,18 @@ struct KernelArgs {
   uint32_t op;                // kModeTrace: 0 = camera transform, 1 = reflect
   uint32_t img_w;             // > 0: rays are a row-major img_w x img_h image, walked in 8x8 pixel tiles per wave
   uint32_t img_h;
+  uint32_t tiles_x;           // image: ceil(img_w / 8), and the multiplier that divides a tile index by it:
+  uint32_t tiles_x_magic;     //   floor(2^32 / tiles_x) + 1 (mulhi gives the quotient or one more); unused when tiles_x == 1
+  uint32_t waves_per_block;   // set by LaunchClosestHit: block / 64
   uint32_t leaf_pct;          // switch from node steps to leaf steps once this percentage of busy lanes hold a leaf
   float scale;                // max |coordinate| of the scene box (slab padding)
   float cam[16];              // kModeTrace: camera matrix; kModePrimary: cam[0..2] = ray origin
   QuantGrid grid;             // quantized layouts only
 };
 
+// done (nullable): event signalled by the kernel's own completion (no separate record packet behind the launch)
 hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool count, uint32_t grid,
-                            uint32_t block, hipStream_t stream);
+                            uint32_t block, hipStream_t stream, hipEvent_t done = nullptr);
 // order[k] = k-th unit to start, costliest bin first, index order within a bin (one 512-thread workgroup).
 // unit_cost must hold 512 * BuildOrderKeysPerThread(nunits) entries; it is zeroed after being read.
 uint32_t BuildOrderKeysPerThread(uint32_t nunits);

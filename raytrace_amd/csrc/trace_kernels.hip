@@ -19,6 +19,7 @@
 //     which is what an index-order brute-force loop with a strict `<` returns
 //     (cpu_raycast/raycast.cpp:113-122).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 
@@ -272,24 +273,37 @@ __device__ __forceinline__ uint32_t NodeStep(const KernelArgs &p, const RayCtx &
 
 __device__ __forceinline__ float Dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-// Where a wave's work unit sits: the first record of a linear run, or the pixel origin of an 8x8 tile.
+// Where a wave's share of a work unit sits: the first record of a linear run, or the pixel origin of a square of pixels.
+// A whole unit is 64 consecutive records, or an 8x8 pixel tile (the reference launches 8x8 work-groups too,
+// img_main.cpp:457-461), which keeps the 64 rays of a wave on neighbouring paths through the tree.  SPLIT kernels also know
+// quarter units, 16 consecutive records or a 4x4 pixel block, held by lanes 0..15 of the wave.
 struct UnitPos {
   uint32_t first;    // linear: index of lane 0's record
   uint32_t x0, y0;   // image: pixel of lane 0
+  uint32_t sub;      // 0 = whole unit, 1 = quarter unit (always 0 outside SPLIT kernels)
 };
 
-// Ray record handled by `lane` of the wave that owns the unit at `u`; false if the lane falls off the ray set.
-// Linear: the unit is 64 consecutive records.  Image: the unit is an 8x8 pixel tile (the reference launches 8x8
-// work-groups too, img_main.cpp:457-461), which keeps the 64 rays of a wave on neighbouring paths through the tree.
+// Pixel of `lane`, row-major over the 8x8 or 4x4 square.
+template <bool SPLIT>
+__device__ __forceinline__ void PixelOfLane(const UnitPos &u, uint32_t lane, uint32_t &x, uint32_t &y)
+{
+  x = u.x0 + (lane & (SPLIT ? 7u >> u.sub : 7u));
+  y = u.y0 + (lane >> (SPLIT ? 3u - u.sub : 3u));
+}
+
+// Ray record handled by `lane` of the wave whose share sits at `u`; false if the lane falls off the share or the ray set.
+template <bool SPLIT>
 __device__ __forceinline__ bool RayOfLane(const KernelArgs &p, const UnitPos &u, uint32_t lane, uint32_t &idx)
 {
+  const bool mine = !SPLIT || lane < (64u >> (2u * u.sub));
   if (p.img_w) {
-    const uint32_t x = u.x0 + (lane & 7u), y = u.y0 + (lane >> 3);
+    uint32_t x, y;
+    PixelOfLane<SPLIT>(u, lane, x, y);
     idx = y * p.img_w + x;
-    return x < p.img_w && y < p.img_h;
+    return mine && x < p.img_w && y < p.img_h;
   }
   idx = u.first + lane;
-  return idx < p.n;
+  return mine && idx < p.n;
 }
 
 #ifndef RT_MIN_WAVES_PER_SIMD
@@ -300,11 +314,15 @@ __device__ __forceinline__ bool RayOfLane(const KernelArgs &p, const UnitPos &u,
 // (at 7 it spills inside the loop and loses a quarter of its speed).
 constexpr int MinWavesPerSimd(int mode) { return mode == kModeTrace ? (RT_MIN_WAVES_PER_SIMD < 6 ? RT_MIN_WAVES_PER_SIMD : 6) : RT_MIN_WAVES_PER_SIMD; }
 
-template <int WIDTH, bool QUANT, int MODE, bool COUNT>
+// SPLIT: the launch traces the first p.split_units units of its order with four waves each (a quarter of the unit per wave).
+template <int WIDTH, bool QUANT, int MODE, bool COUNT, bool SPLIT>
 __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(KernelArgs p)
 {
   extern __shared__ uint2 lds_stack[];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // the wave's index is the same in all of its lanes: saying so keeps what depends on it (the dispatch slot, the order lookup,
+  // the unit's position) in scalar registers and scalar loads, off the vector memory path the rays are about to need
+  // (the LDS stack's base stays a per-lane vector value, as every access to it wants it)
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint2 *const wave_lds = lds_stack + wave * p.stack_entries * 64u;   // stack_entries >= 8: 4 KB for the record exchange
   uint2 deep[kDeepEntries];   // private memory; touched only by rays whose stack outgrows the LDS part
 
@@ -319,31 +337,42 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
       if (lane == 0) got = atomicAdd(p.cursor, 1u);
       slot = __builtin_amdgcn_readfirstlane(got);
     } else {
-      slot = blockIdx.x * (blockDim.x >> 6) + wave;
+      slot = blockIdx.x * p.waves_per_block + wave_s;
     }
-    if (slot >= p.ntasks) return;
+    if (slot >= p.ntasks + (SPLIT ? 3u * p.split_units : 0u)) return;
     unsigned long long t_start = 0;
     if (COUNT && p.timeline) t_start = __builtin_amdgcn_s_memrealtime();
     // Which work unit this wave takes: the slot-th entry of the dispatch order.  The order comes from an earlier
     // launch's measured costs (costliest first, so the few long-running waves start first instead of being the
     // last ones alive) or, failing that, runs from the image centre out.
-    uint32_t unit = slot;
-    if (p.order) unit = p.order[slot];
-    unit = __builtin_amdgcn_readfirstlane(unit);   // the same for every lane: keeps the index arithmetic scalar
-    if (unit >= p.ntasks) unit = slot;             // a stale order table may cost time, never an out-of-range access
+    // The first split_units entries of the order are taken by four consecutive slots each, a quarter of the unit per wave.
+    const bool quarter = SPLIT && slot < 4u * p.split_units;
+    const uint32_t entry = !SPLIT ? slot : (quarter ? slot >> 2 : slot - 3u * p.split_units);
+    uint32_t unit = entry;
+    if (p.order) {
+      // one scalar load (an earlier kernel wrote the table): a vector load here would put a vector-memory round trip, the
+      // slowest kind on a busy CU, in front of the wave's ray loads
+      asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(unit) : "s"(p.order + entry) : "memory");
+    }
+    if (unit >= p.ntasks) unit = entry;            // a stale order table may cost time, never an out-of-range access
     // The launch ends with its longest-lived wave.  Under a costliest-first order those are the first slots: they
     // get the SIMD's issue priority, so that their long dependent chains are not stretched by waiting for the
     // instruction slots of the short waves that come and go beside them.
     if (slot < p.prio_slots) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);
-    UnitPos pos{unit * 64u, 0u, 0u};
-    if (p.img_w) {
-      const uint32_t tiles_x = (p.img_w + 7u) >> 3, ty = unit / tiles_x;
-      pos.x0 = (unit - ty * tiles_x) * 8u;
-      pos.y0 = ty * 8u;
+    UnitPos pos{unit * 64u + (quarter ? (slot & 3u) * 16u : 0u), 0u, 0u, quarter ? 1u : 0u};
+    if (p.img_w) {   // the tile's origin, or that of its 4x4 block (slot & 1, slot >> 1 & 1)
+      uint32_t ty = unit;   // unit / tiles_x without a divide: the multiplier's quotient is exact or one too large
+      if (p.tiles_x != 1u) {
+        ty = __umulhi(unit, p.tiles_x_magic);
+        if (ty * p.tiles_x > unit) ty--;
+      }
+      const uint32_t tiles_x = p.tiles_x;
+      pos.x0 = (unit - ty * tiles_x) * 8u + (quarter ? (slot & 1u) * 4u : 0u);
+      pos.y0 = ty * 8u + (quarter ? (slot & 2u) * 2u : 0u);
     }
     uint32_t idx;
-    const bool valid = RayOfLane(p, pos, lane, idx);
+    const bool valid = RayOfLane<SPLIT>(p, pos, lane, idx);
     float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0, rec3 = rec0;   // this lane's output record
     uint32_t wave_cost = 0;
     uint32_t c_node = 0, c_tri = 0, c_leaf = 0, c_hit = 0, c_deep = 0;  // instrumented build: this lane's counts
@@ -355,8 +384,9 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
         // core/raymath.cpp:6-15): eye = (W/2, H/2, -5W), direction = normalize((i, j, 0) - eye), the same float
         // operations in the same order as the host generator, so the rays are bit-identical to its table
         const float ex = p.img_w / 2.f, ey = p.img_h / 2.f, ez = static_cast<float>(-5 * static_cast<int>(p.img_w));
-        const float tx = static_cast<float>(pos.x0 + (lane & 7u)) - ex, ty = static_cast<float>(pos.y0 + (lane >> 3)) - ey,
-                    tz = 0.f - ez;
+        uint32_t px, py;
+        PixelOfLane<SPLIT>(pos, lane, px, py);
+        const float tx = static_cast<float>(px) - ex, ty = static_cast<float>(py) - ey, tz = 0.f - ez;
         const float len = sqrtf(tx * tx + ty * ty + tz * tz);
         in_o = make_float4(p.cam[0], p.cam[1], p.cam[2], 1.f);
         in_d = make_float4(tx / len, ty / len, tz / len, 0.f);
@@ -494,6 +524,15 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
       }
       if (MODE == kModeTrace && p.rgba) StoreStreamF4<MODE != kModeTrace>(reinterpret_cast<float4 *>(p.rgba) + idx, color);
     }
+    // After the traversal loop a SPLIT kernel works out again whether the wave holds a quarter, instead of carrying the answer
+    // through the loop in registers the loop is short of.
+    bool quarter_out = quarter;
+    if (SPLIT) {
+      uint32_t w = threadIdx.x >> 6;
+      asm volatile("" : "+v"(w));
+      quarter_out = blockIdx.x * p.waves_per_block + __builtin_amdgcn_readfirstlane(w) < 4u * p.split_units;   // never with a cursor
+      pos.sub = quarter_out ? 1u : 0u;
+    }
     if (p.hits) {
       // 64-byte records, one per lane: written straight from the lanes, every store instruction would scatter 64
       // 16-byte pieces over 32 cache lines.  The wave's traversal stack is idle by now, so the records are
@@ -512,7 +551,7 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
         const uint32_t src = k * 16u + (lane >> 2), quarter = lane & 3u;
         const float4 v = tile[src * 4u + (quarter ^ ((src >> 2) & 3u))];
         uint32_t src_idx;
-        if (RayOfLane(p, pos, src, src_idx)) StoreStreamF4<MODE != kModeTrace>(reinterpret_cast<float4 *>(p.hits + src_idx) + quarter, v);
+        if (RayOfLane<SPLIT>(p, pos, src, src_idx)) StoreStreamF4<MODE != kModeTrace>(reinterpret_cast<float4 *>(p.hits + src_idx) + quarter, v);
       }
       if (p.cursor) {   // the next round's pushes must not overtake this round's reads of the exchange tile
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -526,17 +565,24 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
       // of the image shift by a tile or two, and the order built from these numbers has to start THOSE tiles
       // early as well, while ordinary tiles keep their own number.  One atomic instruction per wave: lane l
       // handles neighbour l of the (2R+1)^2 window.
-      const uint32_t cost = __builtin_amdgcn_readfirstlane(wave_cost);   // lane 0 always owns a ray
+      // A quarter wave adds its count to the unit's own cell: the sum of the four is at least what the whole unit would
+      // take as one wave, so a unit that was split keeps its rank and stays split while it stays expensive.
+      const uint32_t cost = __builtin_amdgcn_readfirstlane(wave_cost);   // lane 0 owns a ray if any lane does
       const uint32_t side = 2u * p.cost_radius + 1u;
       if (p.img_w) {
         const uint32_t tiles_x = (p.img_w + 7u) >> 3, tiles_y = (p.img_h + 7u) >> 3;
         const uint32_t nx = (pos.x0 >> 3) + lane % side - p.cost_radius, ny = (pos.y0 >> 3) + lane / side - p.cost_radius;
         const bool self = nx == (pos.x0 >> 3) && ny == (pos.y0 >> 3);
-        if (lane < side * side && nx < tiles_x && ny < tiles_y)
-          atomicMax(p.unit_cost + ny * tiles_x + nx, self ? cost : cost * p.cost_share / 128u);
+        if (lane < side * side && nx < tiles_x && ny < tiles_y) {
+          if (self && quarter_out) atomicAdd(p.unit_cost + ny * tiles_x + nx, cost);
+          else atomicMax(p.unit_cost + ny * tiles_x + nx, self ? cost : cost * p.cost_share / 128u);
+        }
       } else {
         const uint32_t nu = unit + lane - p.cost_radius;
-        if (lane < side && nu < p.ntasks) atomicMax(p.unit_cost + nu, nu == unit ? cost : cost * p.cost_share / 128u);
+        if (lane < side && nu < p.ntasks) {
+          if (nu == unit && quarter_out) atomicAdd(p.unit_cost + nu, cost);
+          else atomicMax(p.unit_cost + nu, nu == unit ? cost : cost * p.cost_share / 128u);
+        }
       }
     }
     if (COUNT) {
@@ -706,40 +752,54 @@ __global__ void TriBatchKernel(const rt_vec3 *tri, const rt_ray *ray, uint32_t n
   uv[i].v = v;
 }
 
-template <int WIDTH, bool QUANT, int MODE, bool COUNT>
-hipError_t LaunchOne(const KernelArgs &a, uint32_t grid, uint32_t block, size_t lds, hipStream_t stream)
+// `done` (nullable): an event that the kernel's own completion signals.  Recording an event behind the launch instead puts
+// a separate packet into the queue, and the next launch of the stream then starts ~6-12 us after this one ends.
+template <int WIDTH, bool QUANT, int MODE, bool COUNT, bool SPLIT>
+hipError_t LaunchOne(const KernelArgs &a, uint32_t grid, uint32_t block, size_t lds, hipStream_t stream, hipEvent_t done)
 {
   (void)hipGetLastError();  // the launch status below must be this launch's, not an earlier call's leftover
   if (lds > 64u * 1024u) {  // beyond the default dynamic-LDS limit: ask for what gfx950's 160 KB allow
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ClosestHitKernel<WIDTH, QUANT, MODE, COUNT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ClosestHitKernel<WIDTH, QUANT, MODE, COUNT, SPLIT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((ClosestHitKernel<WIDTH, QUANT, MODE, COUNT>), dim3(grid), dim3(block), lds, stream, a);
+  if (done)
+    hipExtLaunchKernelGGL((ClosestHitKernel<WIDTH, QUANT, MODE, COUNT, SPLIT>), dim3(grid), dim3(block), static_cast<uint32_t>(lds),
+                          stream, nullptr, done, 0u, a);
+  else
+    hipLaunchKernelGGL((ClosestHitKernel<WIDTH, QUANT, MODE, COUNT, SPLIT>), dim3(grid), dim3(block), lds, stream, a);
   return hipGetLastError();
 }
 
 template <int WIDTH, bool QUANT>
 hipError_t LaunchLayout(const KernelArgs &a, int mode, bool count, uint32_t grid, uint32_t block, size_t lds,
-                        hipStream_t stream)
+                        hipStream_t stream, hipEvent_t done)
 {
-  if (count) return LaunchOne<WIDTH, QUANT, kModeIntersect, true>(a, grid, block, lds, stream);
-  if (mode == kModeTrace) return LaunchOne<WIDTH, QUANT, kModeTrace, false>(a, grid, block, lds, stream);
-  if (mode == kModePrimary) return LaunchOne<WIDTH, QUANT, kModePrimary, false>(a, grid, block, lds, stream);
-  return LaunchOne<WIDTH, QUANT, kModeIntersect, false>(a, grid, block, lds, stream);
+  if (count) return LaunchOne<WIDTH, QUANT, kModeIntersect, true, false>(a, grid, block, lds, stream, done);
+  if (mode == kModeTrace) return LaunchOne<WIDTH, QUANT, kModeTrace, false, false>(a, grid, block, lds, stream, done);
+  if (a.split_units) {   // uninstrumented intersection launches only (capi.hip sets split_units for no other)
+    if (mode == kModePrimary) return LaunchOne<WIDTH, QUANT, kModePrimary, false, true>(a, grid, block, lds, stream, done);
+    return LaunchOne<WIDTH, QUANT, kModeIntersect, false, true>(a, grid, block, lds, stream, done);
+  }
+  if (mode == kModePrimary) return LaunchOne<WIDTH, QUANT, kModePrimary, false, false>(a, grid, block, lds, stream, done);
+  return LaunchOne<WIDTH, QUANT, kModeIntersect, false, false>(a, grid, block, lds, stream, done);
 }
 
 }  // namespace
 
-hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool count, uint32_t grid,
-                            uint32_t block, hipStream_t stream)
+hipError_t LaunchClosestHit(const KernelArgs &args, int width, bool quant, int mode, bool count, uint32_t grid,
+                            uint32_t block, hipStream_t stream, hipEvent_t done)
 {
+  KernelArgs a = args;
+  a.waves_per_block = block / 64u;
+  a.tiles_x = (a.img_w + 7u) / 8u;
+  a.tiles_x_magic = a.tiles_x > 1u ? static_cast<uint32_t>((1ull << 32) / a.tiles_x) + 1u : 0u;
   const size_t lds = static_cast<size_t>(a.stack_entries) * 8u * block;  // LDS entries x 8 B x lanes of the workgroup
   if (width == 4)
-    return quant ? LaunchLayout<4, true>(a, mode, count, grid, block, lds, stream)
-                 : LaunchLayout<4, false>(a, mode, count, grid, block, lds, stream);
-  return quant ? LaunchLayout<2, true>(a, mode, count, grid, block, lds, stream)
-               : LaunchLayout<2, false>(a, mode, count, grid, block, lds, stream);
+    return quant ? LaunchLayout<4, true>(a, mode, count, grid, block, lds, stream, done)
+                 : LaunchLayout<4, false>(a, mode, count, grid, block, lds, stream, done);
+  return quant ? LaunchLayout<2, true>(a, mode, count, grid, block, lds, stream, done)
+               : LaunchLayout<2, false>(a, mode, count, grid, block, lds, stream, done);
 }
 
 uint32_t BuildOrderKeysPerThread(uint32_t nunits) { return ((nunits + 511u) / 512u + 31u) / 32u * 32u; }

@@ -429,8 +429,13 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
         dict(image_width=W, leaf_pct=100),
         dict(image_width=W, leaf_pct=37, block_threads=128, width=4),
         dict(image_width=W, quantized=0, feedback=1, width=4),
+        dict(image_width=W, feedback=1, split_units=0, width=4),
+        dict(image_width=W, feedback=1, split_units=7, width=4),
+        dict(image_width=W, feedback=1, split_units=65536, block_threads=256, width=4),   # capped: every unit is split
+        dict(image_width=0, feedback=1, split_units=501, block_threads=128),
+        dict(image_width=W, feedback=1, split_units=100, quantized=0, feedback_radius=0),
     ]
-    defaults = dict(width=2, quantized=1, block_threads=64, image_width=0, leaf_pct=50, persistent=0,
+    defaults = dict(width=2, quantized=1, block_threads=64, image_width=0, leaf_pct=50, persistent=0, split_units=32,
                     persistent_waves=24, lds_stack=10, centre_first=1, feedback=0, feedback_radius=1, feedback_share=96)
     for cfg in settings:
         for k, v in {**defaults, **cfg}.items():
@@ -459,15 +464,16 @@ def test_rays_generated_in_the_kernel_equal_the_table(rt, gpu, W, H):
     scene = rt.Scene(mesh, bvh, device=gpu)
     origin = rt.frame_camera(bvh.root_box, max(W, 16), max(H, 16))
     table = scene.intersect(rt.primary_rays(W, H, origin))
-    for feedback in (0, 1):
+    for feedback, split in ((0, 32), (1, 32), (1, 65536)):   # the last: every tile traced as four quarter waves
         scene.set_param("feedback", feedback)
-        for rep in range(3):
+        scene.set_param("split_units", split)
+        for rep in range(4):
             full = torch.zeros((W * H, 16), dtype=torch.float32, device="cuda")
             compact = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
             scene.trace_primary(W, H, origin, full.data_ptr(), compact.data_ptr())
             torch.cuda.synchronize()
             got = full.cpu().numpy()
-            assert np.array_equal(bits(got), bits(table)), (feedback, rep)
+            assert np.array_equal(bits(got), bits(table)), (feedback, split, rep)
             ids, t, u, v = rt.hit_fields(table)
             c = compact.cpu().numpy()
             assert np.array_equal(c[:, 0].view(np.uint32), ids) and np.array_equal(bits(c[:, 1]), bits(t))

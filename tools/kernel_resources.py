@@ -15,9 +15,9 @@ cur = {}
 def flush():
     if cur:
         n = cur.get("name", "")
-        m = re.search(r"ClosestHitKernelILi(\d)ELb([01])ELi([01])ELb([01])E", n)
+        m = re.search(r"ClosestHitKernelILi(\d)ELb([01])ELi([012])ELb([01])ELb([01])E", n)
         if m:
-            n = "ClosestHit<width=%s quant=%s mode=%s count=%s>" % m.groups()
+            n = "ClosestHit<width=%s quant=%s mode=%s count=%s split=%s>" % m.groups()
         print("%-62s vgpr=%s sgpr=%s scratch=%s waves/simd=%s" % (n, cur.get("v"), cur.get("s"), cur.get("sc"), cur.get("o")))
 
 

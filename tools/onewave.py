@@ -8,8 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytrace_amd as rt
 
 mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, "dragon.obj"), "tolerant")
-bvh = rt.BVH(mesh, "sah")
-scene = rt.Scene(mesh, bvh, device=0)
+bvh = rt.BVH(mesh, os.environ.get("RT_BVH", "fixed"))
+scene = rt.Scene(mesh, bvh, device=0, width=4)
 for kv in (sys.argv[1] if len(sys.argv) > 1 else "").split(","):
     if kv:
         k, v = kv.split("=")
