@@ -76,11 +76,12 @@ constexpr uint32_t kCursorSlots = 64, kCursorStride = 32;   // persistent launch
 // The cost-feedback schedule needs two tables per launch shape: the per-unit cost the trace kernel records
 // and the dispatch order the sort kernel derives from it.  rt_intersect_async keeps them in hipMalloc'd
 // buffers owned by the scene; callers that must not allocate get them from this array instead, one copy
-// per GPU the library runs on, held until the process ends: 2 MiB = 2^18 cost words + 2^18 order words,
-// enough for 2^18 wave-sized work units = 16 Mi rays per call.
+// per GPU the library runs on, held until the process ends: 2 MiB + 32 KiB = 2^18 cost words + 2^18 order words + the sort's
+// 2^13 bin counters, enough for 2^18 wave-sized work units = 16 Mi rays per call.
 constexpr uint32_t kStaticMaxUnits = 1u << 18;
 constexpr size_t kStaticMaxRays = static_cast<size_t>(kStaticMaxUnits) * 64u;
-static __device__ __align__(256) uint32_t scratch[2u * kStaticMaxUnits];
+constexpr uint32_t kStaticBinWords = kStaticMaxUnits / 1024u * static_cast<uint32_t>(rt::kFbBuckets);
+static __device__ __align__(256) uint32_t scratch[2u * kStaticMaxUnits + kStaticBinWords];
 
 // In host code the name `scratch` is only a handle; the array's address on a given GPU comes from
 // hipGetSymbolAddress with that GPU current, once per device, and is what every launch and memset uses.
@@ -129,7 +130,7 @@ struct rt_scene {
   mutable uint32_t *d_order = nullptr;   // cached dispatch order for (order_w, order_h)
   mutable uint32_t order_w = 0, order_h = 0;
   int feedback = 0;              // reuse the previous launch's per-unit cost to start expensive units first
-  mutable uint32_t *d_fb_cost[2] = {nullptr, nullptr}, *d_fb_order[2] = {nullptr, nullptr};
+  mutable uint32_t *d_fb_cost[2] = {nullptr, nullptr}, *d_fb_order[2] = {nullptr, nullptr}, *d_fb_bins = nullptr;
   mutable uint32_t fb_ntasks = 0, fb_n = 0, fb_img_w = 0;  // shape the feedback buffers describe
   mutable bool fb_sorted[2] = {false, false};               // d_fb_order[k] holds (or will hold, after ev_sort[k]) an order
   mutable uint32_t fb_launch = 0;
@@ -233,6 +234,8 @@ int ResetFeedback(const rt_scene *s)
     s->d_fb_cost[k] = s->d_fb_order[k] = nullptr;
     s->fb_sorted[k] = false;
   }
+  if (s->d_fb_bins) (void)hipFree(s->d_fb_bins);
+  s->d_fb_bins = nullptr;
   s->fb_launch = 0;
   s->fb_ntasks = s->fb_n = s->fb_img_w = 0;
   return RT_OK;
@@ -297,13 +300,16 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     if (s->fb_ntasks != a.ntasks || s->fb_n != a.n || s->fb_img_w != a.img_w) {  // new shape: start over
       int rc = ResetFeedback(s);
       if (rc != RT_OK) return rc;
-      const size_t padded = static_cast<size_t>(rt::BuildOrderKeysPerThread(a.ntasks)) * 512u;
+      const size_t padded = rt::OrderPaddedUnits(a.ntasks);
+      RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_bins), rt::OrderBinWords(a.ntasks) * sizeof(uint32_t)));   // sorts run one at a time
       for (int k = 0; k < 2; ++k) {
         RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_cost[k]), padded * sizeof(uint32_t)));
         RT_HIP(hipMemset(s->d_fb_cost[k], 0, padded * sizeof(uint32_t)));
         RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_order[k]), static_cast<size_t>(a.ntasks) * sizeof(uint32_t)));
       }
       if (!s->side) {
+        // default priority: a high-priority side stream whose sort waits on the trace launch of a null-stream caller was
+        // seen to stop both streams for good
         RT_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
         for (int k = 0; k < 2; ++k) {
           RT_HIP(hipEventCreateWithFlags(&s->ev_main[k], hipEventDisableTiming));
@@ -341,6 +347,8 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     const int newest = static_cast<int>((s->fb_launch - 1u) & 1u);
     RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[newest], 0));
     a.order = s->d_fb_order[newest];
+    a.split_units = std::min(static_cast<uint32_t>(s->split_units), a.ntasks);   // ... split like the launches it stands for
+    grid = (a.ntasks + 3u * a.split_units + wpb - 1u) / wpb;
   }
   {
     int rc = CheckStack(s, a, block);
@@ -356,7 +364,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
   if (fb_slot >= 0) {
     // ev_main[fb_slot] is signalled by the trace kernel itself (its launch carried the event)
     RT_HIP(hipStreamWaitEvent(s->side, s->ev_main[fb_slot], 0));
-    RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_order[fb_slot], s->side));
+    RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_bins, s->d_fb_order[fb_slot], s->side));
     RT_HIP(hipEventRecord(s->ev_sort[fb_slot], s->side));
     s->fb_sorted[fb_slot] = true;
     s->fb_launch++;
@@ -801,8 +809,8 @@ int rt_intersect_static(const rt_scene *s, const void *rays_dev, size_t n, void 
                                     std::to_string(kStaticMaxUnits) + ")");
   rc = CheckStack(s, a, 64u);
   if (rc != RT_OK) return rc;
-  uint32_t *cost = st->ptr, *order = st->ptr + kStaticMaxUnits;
-  const size_t padded = static_cast<size_t>(rt::BuildOrderKeysPerThread(a.ntasks)) * 512u;   // <= kStaticMaxUnits
+  uint32_t *cost = st->ptr, *order = st->ptr + kStaticMaxUnits, *bins = st->ptr + 2u * kStaticMaxUnits;
+  const size_t padded = rt::OrderPaddedUnits(a.ntasks);   // <= kStaticMaxUnits, and its bin counters <= kStaticBinWords
   if (st->ntasks != a.ntasks || st->n != a.n || st->img_w != a.img_w) {
     // the array keeps the previous call's contents: a new shape starts from zero costs and no order
     RT_HIP(hipMemsetAsync(cost, 0, padded * sizeof(uint32_t), q));
@@ -816,7 +824,7 @@ int rt_intersect_static(const rt_scene *s, const void *rays_dev, size_t n, void 
   hipError_t e = rt::LaunchClosestHit(a, s->width, s->quant != 0, rt::kModeIntersect, false, a.ntasks, 64u, q);
   if (e != hipSuccess) return FailHip(e, "kernel launch failed");
   // same stream, after the trace: turns this call's costs into the next call's order and zeroes the cost half
-  e = rt::LaunchBuildOrder(cost, a.ntasks, order, q);
+  e = rt::LaunchBuildOrder(cost, a.ntasks, bins, order, q);
   if (e != hipSuccess) {
     st->order_valid = false;
     st->ntasks = 0;   // the cost half may be dirty: start over next time
@@ -1126,7 +1134,7 @@ int rt_scene_wave_timeline(const rt_scene *s, const void *rays_dev, size_t n, ui
   size_t ntasks = (n + 63) / 64;
   if (s->image_width > 0 && n % static_cast<size_t>(s->image_width) == 0)
     ntasks = ((static_cast<size_t>(s->image_width) + 7) / 8) * ((n / s->image_width + 7) / 8);
-  ntasks *= 3;  // room for the slots of a multi-pass launch
+  ntasks *= 4;  // room for the slots of a launch that traces every unit as four quarter waves
   if (capacity < ntasks * 4) return Fail(RT_ERR_INVALID, "timeline buffer too small");
   unsigned long long *d_tl = nullptr;
   RT_HIP(hipMalloc(reinterpret_cast<void **>(&d_tl), ntasks * 4 * sizeof(unsigned long long)));

@@ -13,7 +13,7 @@ namespace rt {
 
 constexpr uint32_t kLeafBitDev = 0x80000000u;
 constexpr int kModeIntersect = 0;  // rays used as given (ray_scene_intersection)
-constexpr int kFbBuckets = 16;     // cost bins of the launch-to-launch feedback schedule
+constexpr int kFbBuckets = 32;     // cost bins of the launch-to-launch feedback schedule
 constexpr int kModeTrace = 1;      // full `trace` step: camera / reflection setup + pixel
 constexpr int kModePrimary = 2;    // rays of the reference's primary table, generated in the kernel (no ray array)
 constexpr uint32_t kDeepEntries = 56;   // traversal-stack entries per lane beyond the LDS part, in private memory
@@ -62,10 +62,12 @@ struct KernelArgs {
 // done (nullable): event signalled by the kernel's own completion (no separate record packet behind the launch)
 hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool count, uint32_t grid,
                             uint32_t block, hipStream_t stream, hipEvent_t done = nullptr);
-// order[k] = k-th unit to start, costliest bin first, index order within a bin (one 512-thread workgroup).
-// unit_cost must hold 512 * BuildOrderKeysPerThread(nunits) entries; it is zeroed after being read.
-uint32_t BuildOrderKeysPerThread(uint32_t nunits);
-hipError_t LaunchBuildOrder(uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream);
+// order[k] = k-th unit to start, costliest bin first, index order within a bin (three small launches on `stream`).
+// unit_cost must hold OrderPaddedUnits(nunits) entries and is zeroed after being read; bins is OrderBinWords(nunits) words
+// of work space.
+uint32_t OrderPaddedUnits(uint32_t nunits);
+uint32_t OrderBinWords(uint32_t nunits);
+hipError_t LaunchBuildOrder(uint32_t *unit_cost, uint32_t nunits, uint32_t *bins, uint32_t *order, hipStream_t stream);
 // dst[pixel] = src[record] for the listed tiles (see ScatterTilesKernel); record_bytes is a multiple of 4.
 hipError_t LaunchScatterTiles(const void *src, uint32_t src_records, const uint32_t *tile_ids, const uint32_t *tile_first, uint32_t ntiles,
                               uint32_t tile, uint32_t img_w, uint32_t img_h, uint32_t record_bytes, void *dst, hipStream_t stream);

@@ -618,82 +618,121 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
   }
 }
 
-// Counting sort of work units by cost bin (cost / 16, capped), costliest bin first, ascending unit index inside
-// a bin so neighbouring units stay neighbours.  One workgroup of 512 threads; thread t owns the contiguous run
-// [t*per, (t+1)*per) and reads it 32 keys at a time as eight independent 16-byte loads, so each pass costs a
-// handful of memory round trips instead of one per key.  unit_cost must be readable and writable up to 512*per
-// entries and is left all zero.
-__device__ __forceinline__ uint32_t CostBin(uint32_t cost) { return min(cost >> 4, static_cast<uint32_t>(kFbBuckets - 1)); }
+// Counting sort of work units by cost bin (cost / 8, capped), costliest bin first, ascending unit index inside a bin so
+// neighbouring units stay neighbours.  Three small launches of ONE-WAVE workgroups: the sort runs on a side stream beside a
+// trace launch that refills every wave slot the moment it frees, and a workgroup of several waves, which needs that many
+// slots of one CU free at the same time, waits there for most of that launch.  Every wave owns a chunk of kOrderChunk
+// consecutive keys (16 per lane, read as four 16-byte loads);
+//   1. OrderCountKernel    bins[bin][chunk] = keys of the chunk in that bin        (bin 0 = the costliest)
+//   2. OrderScanKernel     exclusive prefix sum over bins[][] in bin-major order  = where each (bin, chunk) run starts
+//   3. OrderScatterKernel  ranks the chunk's keys inside each bin in index order and writes the order; zeroes the keys
+// unit_cost must be readable and writable up to OrderPaddedUnits(n) entries and is left all zero.
+constexpr uint32_t kOrderKeys = 16, kOrderChunk = 64u * kOrderKeys;
 
-__global__ void __launch_bounds__(512) BuildOrderKernel(uint32_t *unit_cost, uint32_t n, uint32_t per, uint32_t *order)
+__device__ __forceinline__ uint32_t CostBin(uint32_t cost)
 {
-  __shared__ uint32_t table[kFbBuckets * 512];   // [bin, costliest first][thread]: counts, then next free position
-  __shared__ uint32_t partial[8];
-  const uint32_t t = threadIdx.x, lo = t * per;
-  uint4 *keys4 = reinterpret_cast<uint4 *>(unit_cost + lo);   // per is a multiple of 32
+  return static_cast<uint32_t>(kFbBuckets - 1) - min(cost >> 3, static_cast<uint32_t>(kFbBuckets - 1));
+}
+
+__device__ __forceinline__ void LoadOrderKeys(const uint32_t *unit_cost, uint32_t first, uint32_t (&v)[kOrderKeys])
+{
+  const uint4 *k4 = reinterpret_cast<const uint4 *>(unit_cost + first);
 #pragma unroll
-  for (int b = 0; b < kFbBuckets; ++b) table[b * 512 + t] = 0;
-  // no barrier needed yet: every thread only touches its own column of the table in this pass
-  for (uint32_t c = 0; c < per; c += 32u) {
-    uint4 k[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) k[j] = keys4[c / 4u + j];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t v[4] = {k[j].x, k[j].y, k[j].z, k[j].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (lo + c + 4u * j + e < n) table[(kFbBuckets - 1 - CostBin(v[e])) * 512 + t] += 1u;
-    }
+  for (uint32_t j = 0; j < kOrderKeys / 4u; ++j) {
+    const uint4 k = k4[j];
+    v[4u * j] = k.x; v[4u * j + 1u] = k.y; v[4u * j + 2u] = k.z; v[4u * j + 3u] = k.w;
   }
+}
+
+// Inclusive prefix sum over the 64 lanes of the wave.
+__device__ __forceinline__ uint32_t WaveScan(uint32_t x, uint32_t lane)
+{
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off);
+    if (lane >= static_cast<uint32_t>(off)) x += y;
+  }
+  return x;
+}
+
+__global__ void __launch_bounds__(64) OrderCountKernel(const uint32_t *unit_cost, uint32_t n, uint32_t nchunks, uint32_t *bins)
+{
+  __shared__ uint32_t count[kFbBuckets];
+  const uint32_t t = threadIdx.x, first = blockIdx.x * kOrderChunk + t * kOrderKeys;
+  if (t < static_cast<uint32_t>(kFbBuckets)) count[t] = 0;
   __syncthreads();
-  // exclusive scan over the flat table (bin-major, thread-minor), one bin row at a time: a wave-level scan by
-  // lane shuffles plus the 8 wave totals, so every LDS access is either conflict-free or a broadcast
-  {
-    const uint32_t lane = t & 63u, w = t >> 6;
-    uint32_t base = 0;
-    for (int b = 0; b < kFbBuckets; ++b) {
-      const uint32_t v = table[b * 512 + t];
-      uint32_t x = v;
+  uint32_t v[kOrderKeys];
+  LoadOrderKeys(unit_cost, first, v);
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t y = __shfl_up(x, off);
-        if (lane >= static_cast<uint32_t>(off)) x += y;
-      }
-      if (lane == 63u) partial[w] = x;
-      __syncthreads();
-      uint32_t before = 0, total = 0;
-#pragma unroll
-      for (uint32_t k = 0; k < 8u; ++k) {
-        const uint32_t wt = partial[k];
-        before += k < w ? wt : 0u;
-        total += wt;
-      }
-      table[b * 512 + t] = base + before + x - v;
-      base += total;
-      __syncthreads();
+  for (uint32_t e = 0; e < kOrderKeys; ++e)
+    if (first + e < n) atomicAdd(&count[CostBin(v[e])], 1u);
+  __syncthreads();
+  if (t < static_cast<uint32_t>(kFbBuckets)) bins[t * nchunks + blockIdx.x] = count[t];
+}
+
+// One wave walks the table in tiles of 2048 entries staged in LDS with coalesced accesses (8 KB: a workgroup that asks for
+// more LDS than the trace launch beside it leaves free on a CU waits for that launch to drain); inside a tile lane t sums
+// a contiguous run, the runs' totals are scanned across the lanes, and the tile's total carries into the next.
+constexpr uint32_t kOrderScanTile = 2048;
+
+__global__ void __launch_bounds__(64) OrderScanKernel(uint32_t *bins, uint32_t total)
+{
+  __shared__ uint32_t staged[kOrderScanTile];
+  const uint32_t t = threadIdx.x, per = kOrderScanTile / 64u;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < total; base += kOrderScanTile) {
+    const uint32_t count = min(kOrderScanTile, total - base);
+    for (uint32_t i = t; i < count; i += 64u) staged[i] = bins[base + i];
+    __syncthreads();
+    const uint32_t lo = min(t * per, count), hi = min(lo + per, count);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += staged[i];
+    const uint32_t incl = WaveScan(sum, t);
+    uint32_t run = carry + incl - sum;
+    for (uint32_t i = lo; i < hi; ++i) {
+      const uint32_t c = staged[i];
+      staged[i] = run;
+      run += c;
     }
+    carry += __shfl(incl, 63);
+    __syncthreads();
+    for (uint32_t i = t; i < count; i += 64u) bins[base + i] = staged[i];
+    __syncthreads();
   }
-  for (uint32_t c = 0; c < per; c += 32u) {
-    uint4 k[8];
+}
+
+__global__ void __launch_bounds__(64) OrderScatterKernel(uint32_t *unit_cost, uint32_t n, uint32_t nchunks, const uint32_t *bins,
+                                                        uint32_t *order)
+{
+  __shared__ uint32_t table[kFbBuckets * 64];   // [bin][lane]: counts, then next free position
+  const uint32_t t = threadIdx.x, first = blockIdx.x * kOrderChunk + t * kOrderKeys;
+  // where the chunk's run of bin t starts in the order (kFbBuckets <= 64)
+  const uint32_t start = t < static_cast<uint32_t>(kFbBuckets) ? bins[t * nchunks + blockIdx.x] : 0u;
+  uint32_t v[kOrderKeys];
+  LoadOrderKeys(unit_cost, first, v);
+  {
+    uint4 *k4 = reinterpret_cast<uint4 *>(unit_cost + first);   // the next launch that records into this buffer takes maxima
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      k[j] = keys4[c / 4u + j];
-      keys4[c / 4u + j] = make_uint4(0u, 0u, 0u, 0u);   // the next launch that records into this buffer takes maxima
-    }
+    for (uint32_t j = 0; j < kOrderKeys / 4u; ++j) k4[j] = make_uint4(0u, 0u, 0u, 0u);
+  }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t v[4] = {k[j].x, k[j].y, k[j].z, k[j].w};
+  for (int b = 0; b < kFbBuckets; ++b) table[b * 64 + t] = 0;
+  // every lane only touches its own column of the table
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t i = lo + c + 4u * j + e;
-        if (i < n) {
-          uint32_t *cell = &table[(kFbBuckets - 1 - CostBin(v[e])) * 512 + t];
-          const uint32_t pos = *cell;
-          *cell = pos + 1u;
-          order[pos] = i;
-        }
-      }
+  for (uint32_t e = 0; e < kOrderKeys; ++e)
+    if (first + e < n) table[CostBin(v[e]) * 64u + t] += 1u;
+#pragma unroll
+  for (int b = 0; b < kFbBuckets; ++b) {   // per bin: exclusive scan over the lanes, offset by the run's start
+    const uint32_t c = table[b * 64 + t];
+    table[b * 64 + t] = __shfl(start, b) + WaveScan(c, t) - c;
+  }
+#pragma unroll
+  for (uint32_t e = 0; e < kOrderKeys; ++e) {
+    if (first + e < n) {
+      uint32_t *cell = &table[CostBin(v[e]) * 64u + t];
+      const uint32_t pos = *cell;
+      *cell = pos + 1u;
+      order[pos] = first + e;
     }
   }
 }
@@ -775,9 +814,12 @@ template <int WIDTH, bool QUANT>
 hipError_t LaunchLayout(const KernelArgs &a, int mode, bool count, uint32_t grid, uint32_t block, size_t lds,
                         hipStream_t stream, hipEvent_t done)
 {
-  if (count) return LaunchOne<WIDTH, QUANT, kModeIntersect, true, false>(a, grid, block, lds, stream, done);
+  if (count) {
+    if (a.split_units) return LaunchOne<WIDTH, QUANT, kModeIntersect, true, true>(a, grid, block, lds, stream, done);
+    return LaunchOne<WIDTH, QUANT, kModeIntersect, true, false>(a, grid, block, lds, stream, done);
+  }
   if (mode == kModeTrace) return LaunchOne<WIDTH, QUANT, kModeTrace, false, false>(a, grid, block, lds, stream, done);
-  if (a.split_units) {   // uninstrumented intersection launches only (capi.hip sets split_units for no other)
+  if (a.split_units) {   // intersection launches only (capi.hip sets split_units for no other)
     if (mode == kModePrimary) return LaunchOne<WIDTH, QUANT, kModePrimary, false, true>(a, grid, block, lds, stream, done);
     return LaunchOne<WIDTH, QUANT, kModeIntersect, false, true>(a, grid, block, lds, stream, done);
   }
@@ -802,13 +844,17 @@ hipError_t LaunchClosestHit(const KernelArgs &args, int width, bool quant, int m
                : LaunchLayout<2, false>(a, mode, count, grid, block, lds, stream, done);
 }
 
-uint32_t BuildOrderKeysPerThread(uint32_t nunits) { return ((nunits + 511u) / 512u + 31u) / 32u * 32u; }
+uint32_t OrderPaddedUnits(uint32_t nunits) { return (nunits + kOrderChunk - 1u) / kOrderChunk * kOrderChunk; }
+uint32_t OrderBinWords(uint32_t nunits) { return (nunits + kOrderChunk - 1u) / kOrderChunk * static_cast<uint32_t>(kFbBuckets); }
 
-hipError_t LaunchBuildOrder(uint32_t *unit_cost, uint32_t nunits, uint32_t *order, hipStream_t stream)
+hipError_t LaunchBuildOrder(uint32_t *unit_cost, uint32_t nunits, uint32_t *bins, uint32_t *order, hipStream_t stream)
 {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(BuildOrderKernel, dim3(1), dim3(512), 0, stream, unit_cost, nunits, BuildOrderKeysPerThread(nunits),
-                     order);
+  const uint32_t nchunks = (nunits + kOrderChunk - 1u) / kOrderChunk;
+  if (nchunks == 0) return hipSuccess;
+  hipLaunchKernelGGL(OrderCountKernel, dim3(nchunks), dim3(64), 0, stream, unit_cost, nunits, nchunks, bins);
+  hipLaunchKernelGGL(OrderScanKernel, dim3(1), dim3(64), 0, stream, bins, nchunks * static_cast<uint32_t>(kFbBuckets));
+  hipLaunchKernelGGL(OrderScatterKernel, dim3(nchunks), dim3(64), 0, stream, unit_cost, nunits, nchunks, bins, order);
   return hipGetLastError();
 }
 

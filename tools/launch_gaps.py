@@ -2,9 +2,11 @@
 """Mean duration of the trace kernel and mean idle gap between consecutive trace launches, from a rocprofv3 kernel trace:
    tools/launch_gaps.py <kernel_trace.csv>"""
 import csv
+import re
 import sys
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "ClosestHitKernel" in r["Kernel_Name"] and ", false>" in r["Kernel_Name"]]
+pat = re.compile(r"ClosestHitKernel<\d, (?:true|false), \d, false")   # the uninstrumented trace kernels
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if pat.search(r["Kernel_Name"])]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 gaps = [(int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3 for a, b in zip(rows, rows[1:])]
