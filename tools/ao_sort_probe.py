@@ -15,8 +15,8 @@ def part1by2(x):
     return x
 
 mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, "bunny_big.obj"), "tolerant")
-bvh = rt.BVH(mesh, "sah")
-scene = rt.Scene(mesh, bvh, device=0)
+bvh = rt.BVH(mesh, "fixed")
+scene = rt.Scene(mesh, bvh, device=0, width=4)
 n = 8 << 20
 rays = rt.ao_rays(mesh, bvh.root_box, 1234, 0, n)
 box = bvh.root_box
