@@ -132,6 +132,9 @@ int rt_scene_records(const rt_scene *s, int which, void *out, size_t capacity, s
  *                    kernel on a library-owned side stream turns that into a costliest-first dispatch order,
  *                    which the launch after next of the same shape (ray count, image width) on this scene uses.
  *                    A schedule only: every ray is traced on every launch.  Any change of shape starts over.
+ *   "feedback_period" 1..1024 (default 8, with "feedback"): every this-many launches one records its costs and a
+ *                    sort follows it; the launches between follow the newest finished order unchanged (each sort
+ *                    costs the stream that traces about 6 us).  1 = every launch.
  *   "feedback_radius" 0..3, "feedback_share" 0..128 (with "feedback"): a unit's measured cost also counts, scaled
  *                    by share/128, for the units within `radius` of it (tiles in both image directions), so
  *                    that the order still starts the right tiles first when the camera moved between the

@@ -133,7 +133,11 @@ struct rt_scene {
   mutable uint32_t *d_fb_cost[2] = {nullptr, nullptr}, *d_fb_order[2] = {nullptr, nullptr}, *d_fb_bins = nullptr;
   mutable uint32_t fb_ntasks = 0, fb_n = 0, fb_img_w = 0;  // shape the feedback buffers describe
   mutable bool fb_sorted[2] = {false, false};               // d_fb_order[k] holds (or will hold, after ev_sort[k]) an order
+  mutable bool fb_pending[2] = {false, false};              // ... whose sort has not yet been seen to finish
   mutable uint32_t fb_launch = 0;
+  mutable uint32_t fb_since_sort = 0;                       // launches since the last one that recorded costs
+  mutable int fb_cur = 0, fb_newest = 0;                    // set the launches record into; set of the sort enqueued last
+  int feedback_period = 8;                                  // every this-many launches one records its costs and a sort follows it
   mutable hipStream_t side = nullptr;                       // the order-building kernel runs here, beside the next trace
   mutable hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_sort[2] = {nullptr, nullptr};
   int waves_per_cu = 0;          // optional resident-wave cap per CU, held through the LDS stack size (0 = none)
@@ -232,8 +236,10 @@ int ResetFeedback(const rt_scene *s)
     if (s->d_fb_cost[k]) (void)hipFree(s->d_fb_cost[k]);
     if (s->d_fb_order[k]) (void)hipFree(s->d_fb_order[k]);
     s->d_fb_cost[k] = s->d_fb_order[k] = nullptr;
-    s->fb_sorted[k] = false;
+    s->fb_sorted[k] = s->fb_pending[k] = false;
   }
+  s->fb_since_sort = 0;
+  s->fb_cur = s->fb_newest = 0;
   if (s->d_fb_bins) (void)hipFree(s->d_fb_bins);
   s->d_fb_bins = nullptr;
   s->fb_launch = 0;
@@ -296,6 +302,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     RT_HIP(hipMemsetAsync(a.cursor, 0, sizeof(uint32_t), stream));
   }
   int fb_slot = -1;
+  bool sort_now = false;   // this launch ends a period of the cost feedback: it records its costs and a sort follows it
   if (s->feedback == 1 && !count && !plain && a.n < kFeedbackMaxRays) {
     if (s->fb_ntasks != a.ntasks || s->fb_n != a.n || s->fb_img_w != a.img_w) {  // new shape: start over
       int rc = ResetFeedback(s);
@@ -318,18 +325,31 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
       }
       s->fb_ntasks = a.ntasks; s->fb_n = a.n; s->fb_img_w = a.img_w;
     }
-    // Launch k traces in the order sorted from launch k-2's costs; the sort of launch k-1's costs runs on the
-    // side stream next to this launch and is ready for launch k+1.  Set `fb_slot` alternates between the two.
-    fb_slot = static_cast<int>(s->fb_launch & 1u);
-    if (s->fb_sorted[fb_slot]) {
-      // that sort ran beside the previous launch and has normally finished long ago: only a sort still running puts a
-      // wait (one more packet ahead of the trace kernel) into the stream
-      if (hipEventQuery(s->ev_sort[fb_slot]) != hipSuccess) {
-        (void)hipGetLastError();
-        RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[fb_slot], 0));
-      }
-      a.order = s->d_fb_order[fb_slot];
+    // Every `feedback_period`-th launch records its per-unit costs into set `fb_cur`; a sort of that set is enqueued on the
+    // side stream behind it and the next recording goes to the other set (the first two periods are one launch long, so
+    // that an order exists from the third launch on).  A launch follows the newest order whose sort has finished -- with
+    // a period of one that is the order from two launches back, sorted beside the launch before this one.  Each sort
+    // costs the main stream about 6 us (the completion signal the side stream waits for, and the sort's waves among the
+    // next launch's), which the period spreads over its launches.
+    fb_slot = s->fb_cur;
+    sort_now = s->fb_since_sort + 1u >= static_cast<uint32_t>(s->feedback_period) || s->fb_launch < 2u;
+    for (int k = 0; k < 2; ++k)
+      if (s->fb_pending[k] && hipEventQuery(s->ev_sort[k]) == hipSuccess) s->fb_pending[k] = false;
+    (void)hipGetLastError();   // hipErrorNotReady from a query is not an error of this call
+    bool waited = false;
+    if (sort_now && s->fb_pending[fb_slot]) {
+      // the sort that reads and zeroes this set's costs is still running: no launch may record into it yet
+      RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[fb_slot], 0));
+      waited = true;
     }
+    int use = -1;
+    for (int k : {s->fb_newest, 1 - s->fb_newest})
+      if (use < 0 && s->fb_sorted[k] && (!s->fb_pending[k] || (waited && k == fb_slot))) use = k;
+    if (use < 0 && s->fb_sorted[s->fb_newest]) {
+      use = s->fb_newest;
+      RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[use], 0));
+    }
+    if (use >= 0) a.order = s->d_fb_order[use];
     if (a.order && !a.cursor && mode != rt::kModeTrace) {
       // The launch cannot end before its longest wave does, and a wave's length is the number of traversal steps its 64 rays
       // need between them.  The costliest units are therefore cut into four (16 rays per wave, 4x4 pixels or 16 records):
@@ -338,13 +358,16 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
       grid = (a.ntasks + 3u * a.split_units + wpb - 1u) / wpb;
     }
     if (a.order) a.prio_slots = static_cast<uint32_t>(static_cast<uint64_t>(a.ntasks) * static_cast<uint32_t>(s->prio_permille) / 1000u);
-    a.unit_cost = s->d_fb_cost[fb_slot];
+    // only the launch that ends a period records its costs: the others save the atomics, and an order from one camera
+    // position served the launches after it better than the maximum over a period's positions did (+2 %)
+    a.unit_cost = sort_now ? s->d_fb_cost[fb_slot] : nullptr;
     a.cost_radius = static_cast<uint32_t>(s->feedback_radius);
     a.cost_share = static_cast<uint32_t>(s->feedback_share);
   }
-  if (s->feedback == 1 && count && !plain && s->fb_launch >= 1u && s->fb_ntasks == a.ntasks && s->fb_n == a.n && s->fb_img_w == a.img_w) {
+  if (s->feedback == 1 && count && !plain && s->fb_sorted[s->fb_newest] && s->fb_ntasks == a.ntasks && s->fb_n == a.n && s->fb_img_w == a.img_w) {
     // instrumented launch: follow the newest cost-sorted order, read-only
-    const int newest = static_cast<int>((s->fb_launch - 1u) & 1u);
+    const int newest = s->fb_newest;
+    if (!s->fb_sorted[newest]) return Fail(RT_ERR_INVALID, "internal: no cost-sorted order yet");
     RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[newest], 0));
     a.order = s->d_fb_order[newest];
     a.split_units = std::min(static_cast<uint32_t>(s->split_units), a.ntasks);   // ... split like the launches it stands for
@@ -356,19 +379,24 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
   }
   {
     hipError_t e_ = rt::LaunchClosestHit(a, s->width, s->quant != 0, mode, count, grid, block, stream,
-                                         fb_slot >= 0 ? s->ev_main[fb_slot] : nullptr);
+                                         sort_now ? s->ev_main[fb_slot] : nullptr);
     if (e_ != hipSuccess)
       return Fail(RT_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(e_) + " (grid " + std::to_string(grid) +
                                      ", block " + std::to_string(block) + ", stack entries " + std::to_string(a.stack_entries) + ")");
   }
-  if (fb_slot >= 0) {
+  if (sort_now) {
     // ev_main[fb_slot] is signalled by the trace kernel itself (its launch carried the event)
     RT_HIP(hipStreamWaitEvent(s->side, s->ev_main[fb_slot], 0));
     RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_bins, s->d_fb_order[fb_slot], s->side));
     RT_HIP(hipEventRecord(s->ev_sort[fb_slot], s->side));
-    s->fb_sorted[fb_slot] = true;
-    s->fb_launch++;
+    s->fb_sorted[fb_slot] = s->fb_pending[fb_slot] = true;
+    s->fb_newest = fb_slot;
+    s->fb_cur = 1 - fb_slot;
+    s->fb_since_sort = 0;
+  } else if (fb_slot >= 0) {
+    s->fb_since_sort++;
   }
+  if (fb_slot >= 0) s->fb_launch++;
   return RT_OK;
 }
 
@@ -727,6 +755,9 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "leaf_pct") {
     if (value < 1 || value > 100) return Fail(RT_ERR_INVALID, "leaf_pct must be in 1..100");
     s->leaf_pct = value;
+  } else if (k == "feedback_period") {
+    if (value < 1 || value > 1024) return Fail(RT_ERR_INVALID, "feedback_period must be in 1..1024");
+    s->feedback_period = value;
   } else if (k == "split_units") {
     if (value < 0 || value > 65536) return Fail(RT_ERR_INVALID, "split_units must be in 0..65536");
     s->split_units = value;

@@ -436,13 +436,16 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
         dict(image_width=W, feedback=1, split_units=65536, block_threads=256, width=4),   # capped: every unit is split
         dict(image_width=0, feedback=1, split_units=501, block_threads=128),
         dict(image_width=W, feedback=1, split_units=100, quantized=0, feedback_radius=0),
+        dict(image_width=W, feedback=1, feedback_period=1, width=4),
+        dict(image_width=W, feedback=1, feedback_period=2, block_threads=128),
+        dict(image_width=0, feedback=1, feedback_period=3, width=4),
     ]
-    defaults = dict(width=2, quantized=1, block_threads=64, image_width=0, leaf_pct=50, persistent=0, split_units=32,
+    defaults = dict(width=2, quantized=1, block_threads=64, image_width=0, leaf_pct=50, persistent=0, split_units=32, feedback_period=4,
                     persistent_waves=24, lds_stack=10, centre_first=1, feedback=0, feedback_radius=1, feedback_share=96)
     for cfg in settings:
         for k, v in {**defaults, **cfg}.items():
             scene.set_param(k, v)
-        for rep in range(4):      # launches 2 and 3 run in an order sorted from launches 0 and 1
+        for rep in range(9):      # from launch 2 on in an order sorted from earlier launches' costs, re-sorted every period
             out = scene.intersect(rays)
             assert np.array_equal(bits(out), bits(base)), (cfg, rep)
     # feedback state survives a change of shape and of rays between launches
