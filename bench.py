@@ -95,7 +95,7 @@ def parse():
                     help="image workloads: distinct camera positions (ray tables, all resident in HBM) the steps cycle "
                          "through, so that no step repeats the previous step's rays")
     ap.add_argument("--feedback", type=int, default=1,
-                    help="1: each launch starts its work units costliest-first, by the costs measured two launches earlier")
+                    help="1: each launch starts its work units costliest-first, by the costs an earlier launch of the same shape measured")
     ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE",
                     help="extra rt_scene_set_param settings (repeatable), applied last")
     return ap.parse_args()
@@ -648,7 +648,7 @@ def main():
                        "hit_record": "64B RayIntersection" if out_b == 64 else ("16B RGBA32F pixel -> 4B BGRA" if (sharded and pix) else "16B {id,t,u,v}"),
                        "frames": frames,
                        "rays": "RayIntersection table resident in HBM" if in_b else "generated in the kernel (rt_trace_primary)",
-                       "dispatch_order": "costliest work unit first, from the costs measured two launches earlier" if a.feedback
+                       "dispatch_order": "costliest work unit first, from the costs a launch 2 to 10 launches earlier measured (re-sorted every 8th launch)" if a.feedback
                        else "image centre first",
                        "parallelism": f"{world} x one process per GPU, " + ("cost-balanced image squares + RCCL gather (beside the next frame's trace) + device scatter"
                                                                             if sharded else "frame-parallel")},

@@ -128,10 +128,10 @@ int rt_scene_records(const rt_scene *s, int which, void *out, size_t capacity, s
  *                    as the reference's 2-D NDRange is (render_client/img_main.cpp:457-461); each wave then
  *                    takes an 8x8 pixel tile.  0 = unstructured: each wave takes 64 consecutive records.
  *   "centre_first"   image mode: 1 dispatches the tiles nearest the image centre first, 0 in row order.
- *   "feedback"       1: every launch records the traversal cost of each wave-sized work unit; a small sort
- *                    kernel on a library-owned side stream turns that into a costliest-first dispatch order,
- *                    which the launch after next of the same shape (ray count, image width) on this scene uses.
- *                    A schedule only: every ray is traced on every launch.  Any change of shape starts over.
+ *   "feedback"       1: launches record the traversal cost of each wave-sized work unit; small sort kernels on
+ *                    a library-owned side stream turn that into a costliest-first dispatch order, which later
+ *                    launches of the same shape (ray count, image width) on this scene use, from the launch
+ *                    after next on.  A schedule only: every ray is traced on every launch.  Any change of shape starts over.
  *   "feedback_period" 1..1024 (default 8, with "feedback"): every this-many launches one records its costs and a
  *                    sort follows it; the launches between follow the newest finished order unchanged (each sort
  *                    costs the stream that traces about 6 us).  1 = every launch.
