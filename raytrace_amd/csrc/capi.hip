@@ -140,6 +140,13 @@ struct rt_scene {
   int feedback_period = 8;                                  // every this-many launches one records its costs and a sort follows it
   mutable hipStream_t side = nullptr;                       // the order-building kernel runs here, beside the next trace
   mutable hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_sort[2] = {nullptr, nullptr};
+  // Launches of one scene may go to several streams.  A sort overwrites an order table that launches on OTHER streams than
+  // the one it follows may still be reading, so whenever the feedback launches change stream, an event recorded on the
+  // stream being left marks everything enqueued there so far; the next sort waits for all of those (none in one-stream use).
+  mutable hipStream_t fb_last_stream = nullptr;
+  mutable bool fb_have_last = false;
+  mutable std::vector<hipEvent_t> fb_left;      // pool of events, the first fb_left_used of them recorded since the last sort
+  mutable size_t fb_left_used = 0;
   int waves_per_cu = 0;          // optional resident-wave cap per CU, held through the LDS stack size (0 = none)
   int split_units = 32;          // with a cost-sorted order: this many units, the costliest, are traced by four waves each
   int prio_permille = 0;         // with a cost-sorted order: this share (1/1000) of the leading dispatch slots runs at raised priority
@@ -243,6 +250,8 @@ int ResetFeedback(const rt_scene *s)
   if (s->d_fb_bins) (void)hipFree(s->d_fb_bins);
   s->d_fb_bins = nullptr;
   s->fb_launch = 0;
+  s->fb_left_used = 0;
+  s->fb_have_last = false;
   s->fb_ntasks = s->fb_n = s->fb_img_w = 0;
   return RT_OK;
 }
@@ -384,9 +393,23 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
       return Fail(RT_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(e_) + " (grid " + std::to_string(grid) +
                                      ", block " + std::to_string(block) + ", stack entries " + std::to_string(a.stack_entries) + ")");
   }
+  if (fb_slot >= 0) {
+    if (s->fb_have_last && s->fb_last_stream != stream) {
+      if (s->fb_left_used == s->fb_left.size()) {
+        hipEvent_t e = nullptr;
+        RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->fb_left.push_back(e);
+      }
+      RT_HIP(hipEventRecord(s->fb_left[s->fb_left_used++], s->fb_last_stream));
+    }
+    s->fb_last_stream = stream;
+    s->fb_have_last = true;
+  }
   if (sort_now) {
     // ev_main[fb_slot] is signalled by the trace kernel itself (its launch carried the event)
     RT_HIP(hipStreamWaitEvent(s->side, s->ev_main[fb_slot], 0));
+    for (size_t k = 0; k < s->fb_left_used; ++k) RT_HIP(hipStreamWaitEvent(s->side, s->fb_left[k], 0));
+    s->fb_left_used = 0;
     RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_bins, s->d_fb_order[fb_slot], s->side));
     RT_HIP(hipEventRecord(s->ev_sort[fb_slot], s->side));
     s->fb_sorted[fb_slot] = s->fb_pending[fb_slot] = true;
@@ -684,6 +707,7 @@ void rt_scene_destroy(rt_scene *s)
   if (s->side) {
     (void)hipStreamDestroy(s->side);
     for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(s->ev_main[k]); (void)hipEventDestroy(s->ev_sort[k]); }
+    for (hipEvent_t e : s->fb_left) (void)hipEventDestroy(e);
   }
   (void)hipFree(s->d_stage_in); (void)hipFree(s->d_stage_out);
   for (int k = 0; k < 2; ++k) {

@@ -364,6 +364,44 @@ def test_device_pointers_streams_and_errors(rt, oracle, gpu):
                                   gpu, 3, C.byref(h)) == -1
 
 
+def test_one_scene_on_several_streams_with_the_cost_feedback(rt, gpu):
+    """Launches of one scene may go to any streams.  With the cost feedback on, the sort that rewrites a dispatch-order
+    table must wait for readers on every stream, not only the one it follows: sixty launches dealt to three streams
+    (each with its own hit buffer, re-sorted every second launch, the costliest units split) all return the bits of a
+    launch without feedback."""
+    import torch
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny.obj"), "tolerant")
+    bvh = rt.BVH(mesh, "fixed")
+    W, H = 640, 360
+    rays = framed_primary(rt, bvh, W, H)
+    scene = rt.Scene(mesh, bvh, device=gpu, width=4)
+    scene.set_param("image_width", W)
+    scene.set_param("feedback", 0)
+    d_rays = torch.from_numpy(rays).cuda()
+    base = torch.zeros((len(rays), 4), dtype=torch.float32, device="cuda")
+    scene.intersect_async(d_rays.data_ptr(), len(rays), None, base.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    scene.set_param("feedback", 1)
+    scene.set_param("feedback_period", 2)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [torch.zeros_like(base) for _ in range(3)]
+    for k in range(60):
+        i = (k * 7 + k // 5) % 3          # an irregular deal, including runs on one stream
+        scene.intersect_async(d_rays.data_ptr(), len(rays), None, outs[i].data_ptr(), streams[i].cuda_stream)
+        if k % 20 == 19:
+            torch.cuda.synchronize()
+            for o in outs:
+                assert torch.equal(o.view(torch.int32), base.view(torch.int32)), k
+                o.zero_()
+            # every buffer gets traced again before the next check
+            for i2 in range(3):
+                scene.intersect_async(d_rays.data_ptr(), len(rays), None, outs[i2].data_ptr(), streams[i2].cuda_stream)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o.view(torch.int32), base.view(torch.int32))
+    scene.close()
+
+
 def test_fetch_counters_agree_between_host_and_device(rt, gpu):
     import torch
     mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny.obj"), "tolerant")
