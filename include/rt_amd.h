@@ -178,13 +178,13 @@ int rt_intersect_async(const rt_scene *scene, const void *rays_dev, size_t n, vo
 /* rt_intersect_async for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  It computes the same
  * records as rt_intersect_async and always runs the cost-feedback schedule, but keeps the schedule's tables
- * (per-unit cost, dispatch order, sort counters) in a fixed device array of 2 MiB + 32 KiB inside the library instead of
- * hipMalloc'd buffers: after rt_scene_create the call performs no hipMalloc / hipFree and creates no stream or
- * event; the order kernels run on `stream` behind the trace kernel.  Limit: n <= 16 Mi rays (2^18 wave-sized
- * work units) per call, larger n fails with RT_ERR_INVALID.  Every call on one GPU, whatever the scene, shares
- * that GPU's array: calls that overlap in time on one GPU race on the schedule tables (the hits stay correct
- * only if the calls are ordered, e.g. on one stream); the tables keep the previous call's contents and are
- * cleared on `stream` when the shape (ray count, image width) changes. */
+ * (per-unit cost, dispatch order, sort counters) in a fixed device array of 2 MiB + 32 KiB inside the library
+ * instead of hipMalloc'd buffers: after rt_scene_create the call performs no hipMalloc / hipFree and creates no
+ * stream or event; the order kernels run on `stream` behind the trace kernel of every "feedback_period"-th call.
+ * Limit: n <= 16 Mi rays (2^18 wave-sized work units) per call, larger n fails with RT_ERR_INVALID.  Every call
+ * on one GPU, whatever the scene, shares that GPU's array: calls that overlap in time on one GPU race on the
+ * schedule tables (the hits stay correct only if the calls are ordered, e.g. on one stream); the tables keep the
+ * previous call's contents and are cleared on `stream` when the shape (ray count, image width) changes. */
 int rt_intersect_static(const rt_scene *scene, const void *rays_dev, size_t n, void *hits_dev, void *hits16_dev,
                         void *stream);
 

@@ -90,6 +90,7 @@ struct StaticState {
   uint32_t *ptr = nullptr;      // device address of `scratch` on this GPU
   uint32_t ntasks = 0, n = 0, img_w = 0;   // shape the tables currently describe
   bool order_valid = false;     // the order half holds a schedule for that shape
+  uint32_t since_sort = 0;      // calls since the last one that recorded costs and was followed by a sort
 };
 StaticState g_static[kMaxDevices];
 std::mutex g_static_mutex;   // guards the one-time address lookup only
@@ -872,13 +873,20 @@ int rt_intersect_static(const rt_scene *s, const void *rays_dev, size_t n, void 
     st->ntasks = a.ntasks; st->n = a.n; st->img_w = a.img_w;
     st->order_valid = false;
   }
+  // as in rt_intersect_async: only every feedback_period-th call (and the first of a shape) records costs and re-sorts
+  const bool sort_now = !st->order_valid || st->since_sort + 1u >= static_cast<uint32_t>(s->feedback_period);
   a.order = st->order_valid ? order : nullptr;
-  a.unit_cost = cost;
+  a.unit_cost = sort_now ? cost : nullptr;
   a.cost_radius = static_cast<uint32_t>(s->feedback_radius);
   a.cost_share = static_cast<uint32_t>(s->feedback_share);
   hipError_t e = rt::LaunchClosestHit(a, s->width, s->quant != 0, rt::kModeIntersect, false, a.ntasks, 64u, q);
   if (e != hipSuccess) return FailHip(e, "kernel launch failed");
-  // same stream, after the trace: turns this call's costs into the next call's order and zeroes the cost half
+  if (!sort_now) {
+    st->since_sort++;
+    return RT_OK;
+  }
+  st->since_sort = 0;
+  // same stream, after the trace: turns this call's costs into the next calls' order and zeroes the cost half
   e = rt::LaunchBuildOrder(cost, a.ntasks, bins, order, q);
   if (e != hipSuccess) {
     st->order_valid = false;

@@ -15,6 +15,7 @@ def test_static_entry_point_equals_the_allocating_one():
     mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, "teapot.obj"), "tolerant")
     bvh = rt.BVH(mesh, "fixed")
     scene = rt.Scene(mesh, bvh, device=0)
+    scene.set_param("feedback_period", 2)   # costs recorded and re-sorted by every second call
     try:
         for (W, H), hint in (((640, 360), 640), ((320, 200), 320), ((320, 200), 0)):
             rays = rt.primary_rays(W, H, rt.frame_camera(bvh.root_box, W, H))
@@ -26,7 +27,7 @@ def test_static_entry_point_equals_the_allocating_one():
             scene.intersect_async(rays_d.data_ptr(), n, want.data_ptr(), want16.data_ptr())
             torch.cuda.synchronize()
             assert int((want[:, 14].view(torch.int32) != -1).sum()) > 0
-            for rep in range(3):   # rep 0 runs without an order, rep 1 and 2 with the order built by the call before
+            for rep in range(5):   # rep 0 runs without an order, the others with the order built behind rep 0, then rep 2
                 got = torch.full((n, 16), -7.0, dtype=torch.float32, device="cuda")
                 got16 = torch.full((n, 4), -7.0, dtype=torch.float32, device="cuda")
                 scene.intersect_static(rays_d.data_ptr(), n, got.data_ptr(), got16.data_ptr())
