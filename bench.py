@@ -33,9 +33,11 @@ bounded sample.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import time
+import types
 
 import numpy as np
 import torch  # before raytrace_amd: both must bind the same HIP runtime
@@ -81,9 +83,10 @@ def parse():
     ap.add_argument("--gather", default="hits16", choices=["hits16", "bgra8"],
                     help="tiles4k: what crosses the GPUs into rank 0's framebuffer: the 16-byte {id,t,u,v} hit of every pixel, or its "
                          "shaded 8-bit BGRA pixel (the full trace step + rt_pack_bgra8: a quarter of the bytes)")
-    ap.add_argument("--pipeline", type=int, default=1,
+    ap.add_argument("--pipeline", type=int, default=2, choices=[0, 1, 2],
                     help="tiles4k: 1 = the exchange of a frame runs beside the trace of the next one (two frames in flight, "
-                         "double-buffered); 0 = trace, exchange, scatter one after the other")
+                         "double-buffered); 2 = also on two streams, so the traces of the two frames overlap; "
+                         "0 = trace, exchange, scatter one after the other")
     ap.add_argument("--image-hint", type=int, default=1, help="declare the ray array as a W-wide image (8x8 tiles per wave)")
     ap.add_argument("--raygen", default="table", choices=["table", "device"],
                     help="table: rays are a RayIntersection array resident in HBM (the reference's interface); device: "
@@ -91,6 +94,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 flow on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--share-of", type=int, default=0, metavar="R",
+                    help="rehearsal on one GPU (tiles4k, --gpus 1, with --no-cpu-baseline): trace, scatter and time only the "
+                         "squares rank 0 of R ranks would get, i.e. the per-rank part of an R-GPU step without the exchange")
     ap.add_argument("--frames", type=int, default=4,
                     help="image workloads: distinct camera positions (ray tables, all resident in HBM) the steps cycle "
                          "through, so that no step repeats the previous step's rays")
@@ -201,6 +207,9 @@ def main():
             # iteration counts), so all ranks derive the same assignment without exchanging anything
             costs = tl.tile_costs_from_units(scene.unit_costs_primary(W, H, origin), W, H, a.tile)
             all_lists = tl.assign_tiles(tx * ty, world, costs if a.assign == "cost" else None)
+            if a.share_of > 1 and world == 1:
+                all_lists = [tl.assign_tiles(tx * ty, a.share_of, costs if a.assign == "cost" else None)[0]]
+                extra["rehearsal"] = f"rank 0's share of {a.share_of} ranks on one GPU, no exchange; value counts only those rays"
             idx, _ = tl.rays_of_tiles(W, H, a.tile, all_lists[rank])
             full = rt.primary_rays(W, H, origin)
             rays_h = full[idx]
@@ -241,8 +250,10 @@ def main():
         cam = np.eye(4, dtype=np.float32)
 
     # ---- sharded image: gather buffers, square lists and the exchange --------------------------------------
-    if sharded:
-        pix = a.gather == "bgra8"
+    cam = np.eye(4, dtype=np.float32)
+
+    def build_sharded(pix):
+        """Buffers and closures of the sharded frame for one kind of gathered record: 16-byte hits (pix False) or 8-bit pixels."""
         rec_b = 4 if pix else 16
 
         def records(nrec):
@@ -251,9 +262,23 @@ def main():
         counts = [len(tl.rays_of_tiles(W, H, a.tile, l)[0]) for l in all_lists]
         bases = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         NB = 2     # frames in flight: the exchange of one runs beside the trace of the next
+        # --pipeline 2: the two frames in flight also live on two streams (trace, exchange and scatter of frame buffer b on
+        # stream b), so the tail of one rank-sized launch -- a handful of long waves on an otherwise idle chip, most of the
+        # launch once a frame is cut into N parts -- overlaps the head of the next frame's.
+        two = {"on": a.pipeline == 2}
+        tstreams = [torch.cuda.Stream(), torch.cuda.Stream()] if a.pipeline == 2 else None
+
+        def on_stream(b):
+            return torch.cuda.stream(tstreams[b]) if two["on"] else contextlib.nullcontext()
+
+        def raw_stream(b):
+            return tstreams[b].cuda_stream if two["on"] else stream
+
+        fb_last = [None]
         if rank == 0:
             gather_d = [records(W * H) for _ in range(NB)]       # squares of rank 0, 1, ... back to back
-            fb_d = records(W * H)                                # the row-major framebuffer
+            fbs = [records(W * H) for _ in range(NB if a.pipeline == 2 else 1)]   # the row-major framebuffer(s), one per stream
+            fb_last[0] = fbs[0]
             ids_h = np.concatenate(all_lists).astype(np.int32)
             first_h = np.concatenate([tl.rays_of_tiles(W, H, a.tile, l)[1].astype(np.int64) + bases[r]
                                       for r, l in enumerate(all_lists)]).astype(np.int32)
@@ -262,42 +287,46 @@ def main():
             slices = [[g[bases[r]:bases[r + 1]] for r in range(world)] for g in gather_d]
         else:
             mine = [records(n_local) for _ in range(NB)]
-        hits_d = mine[0]
+            fbs = []
         if pix:
-            rgba_d = torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
-            cam = np.eye(4, dtype=np.float32)
+            rgba_ds = [torch.empty((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(NB)]
         pending = [None] * NB
 
         def trace_into(b):
+            q = raw_stream(b)
             if pix:   # the full trace step (identity camera) writes the RGBA32F pixel; packed to 8-bit BGRA for the wire
-                scene.trace_pass(rays_d.data_ptr(), None, rgba_d.data_ptr(), n_local, cam, 0, stream)
-                rt.pack_bgra8(local, rgba_d.data_ptr(), n_local, mine[b].data_ptr(), stream)
+                scene.trace_pass(rays_d.data_ptr(), None, rgba_ds[b].data_ptr(), n_local, cam, 0, q)
+                rt.pack_bgra8(local, rgba_ds[b].data_ptr(), n_local, mine[b].data_ptr(), q)
             else:
-                scene.intersect_async(rays_d.data_ptr(), n_local, None, mine[b].data_ptr(), stream)
+                scene.intersect_async(rays_d.data_ptr(), n_local, None, mine[b].data_ptr(), q)
 
         def start_exchange(b):
             """Every other rank's records of frame buffer b to rank 0 (point-to-point, grouped: rank 0 receives on its seven
             xGMI links at once, no ring).  Returns the handles still to be waited for."""
             if world == 1:
                 return []
-            if rank == 0:
-                ops = [dist.P2POp(dist.irecv, slices[b][r], r) for r in range(1, world)]
-            else:
-                ops = [dist.P2POp(dist.isend, mine[b], 0)]
-            if a.backend == "nccl":
-                return dist.batch_isend_irecv(ops)
-            for q in [op.op(op.tensor, op.peer) for op in ops]:
-                q.wait()
+            with on_stream(b):   # the collective orders itself behind what the CURRENT stream holds: frame buffer b's trace
+                if rank == 0:
+                    ops = [dist.P2POp(dist.irecv, slices[b][r], r) for r in range(1, world)]
+                else:
+                    ops = [dist.P2POp(dist.isend, mine[b], 0)]
+                if a.backend == "nccl":
+                    return dist.batch_isend_irecv(ops)
+                for q in [op.op(op.tensor, op.peer) for op in ops]:
+                    q.wait()
             return []
 
         def finish_exchange(b):
             """Waits (on the stream, not the host) for frame buffer b's records, then scatters them into the framebuffer."""
-            for q in pending[b] or []:
-                q.wait()
+            with on_stream(b):
+                for q in pending[b] or []:
+                    q.wait()
             pending[b] = None
             if rank == 0:
+                fb = fbs[b if two["on"] else 0]
                 rt.scatter_tiles(local, gather_d[b].data_ptr(), W * H, ids_d.data_ptr(), first_d.data_ptr(), len(ids_h), a.tile, W, H, rec_b,
-                                 fb_d.data_ptr(), stream)
+                                 fb.data_ptr(), raw_stream(b))
+                fb_last[0] = fb
 
         def exchange():
             pending[0] = start_exchange(0)
@@ -321,6 +350,14 @@ def main():
             for b in range(NB):
                 if pending[b] is not None:
                     finish_exchange(b)
+        return types.SimpleNamespace(pix=pix, rec_b=rec_b, records=records, counts=counts, two=two, NB=NB, mine=mine,
+                                     fbs=fbs, fb_last=fb_last, trace_into=trace_into, exchange=exchange, step=step_sharded, flush=flush)
+
+    if sharded:
+        sh = build_sharded(a.gather == "bgra8")
+        pix, rec_b, records, counts, two, NB = sh.pix, sh.rec_b, sh.records, sh.counts, sh.two, sh.NB
+        fbs, fb_last, trace_into, exchange, step_sharded, flush = sh.fbs, sh.fb_last, sh.trace_into, sh.exchange, sh.step, sh.flush
+        hits_d = sh.mine[0]
 
     def step():
         k = step_no[0] % frames
@@ -375,6 +412,17 @@ def main():
         extra["gather_bytes_into_rank0"] = int((W * H - counts[0]) * rec_b)
         extra["gathered_record"] = "8-bit BGRA pixel (full trace step + rt_pack_bgra8)" if pix else "16 B {id,t,u,v}"
         extra["frames_in_flight"] = NB if a.pipeline else 1
+        extra["streams"] = 2 if a.pipeline == 2 else 1
+        if a.pipeline == 2:
+            # the same pipelined steps with both frames in flight on ONE stream: every launch waits for the one before it
+            two["on"] = False
+            w_1, _ = timed(dist, sub, step, flush)
+            two["on"] = True
+            t1 = torch.tensor([w_1], dtype=torch.float64, device=red_dev)
+            if dist:
+                dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+            ms_1 = float(t1.item()) * 1e3 / sub
+            extra["same_steps_on_one_stream"] = {"ms_per_step": round(ms_1, 4), "value": round(n_total / (ms_1 * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
         if world > 1:
             # the whole frame on ONE GPU of this job (rank 0 alone, the others wait): the strong-scaling reference point
             if rank == 0:
@@ -401,16 +449,31 @@ def main():
                                                "unit": "Mrays/s", "speedup_of_this_job": round(one_ms / ms_per_step, 3)}
                 # the gathered framebuffer must be the single-GPU framebuffer, byte for byte
                 scene.set_param("image_width", a.tile if (a.image_hint and W % a.tile == 0) else 0)
-                fb_d.fill_(-1)                   # every frame of the loop is the same image: only a wiped framebuffer proves this step's scatter
+                for fb in fbs:
+                    fb.fill_(-1)                 # every frame of the loop is the same image: only a wiped framebuffer proves this step's scatter
+                torch.cuda.synchronize()
                 step()
                 flush()
                 torch.cuda.synchronize()
-                extra["framebuffer_equals_one_gpu"] = bool(torch.equal(fb_d.view(torch.int32), one_out.view(torch.int32)))
+                extra["framebuffer_equals_one_gpu"] = bool(torch.equal(fb_last[0].view(torch.int32), one_out.view(torch.int32)))
                 del full_d, one_out, one_rgba
             else:
                 step()
                 flush()
             dist.barrier()
+            # the same sharded frame with the other kind of gathered record (a quarter, or four times, the bytes on the links)
+            alt = build_sharded(not pix)
+            for _ in range(max(2, a.warmup // 4)):
+                alt.step()
+            alt.flush()
+            w_a, _ = timed(dist, sub, alt.step, alt.flush)
+            ta = torch.tensor([w_a], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+            ms_a = float(ta.item()) * 1e3 / sub
+            extra["same_frame_gathered_as"] = {"record": "16 B {id,t,u,v}" if pix else "8-bit BGRA pixel (full trace step + rt_pack_bgra8)",
+                                               "gather_bytes_into_rank0": int((W * H - alt.counts[0]) * alt.rec_b),
+                                               "ms_per_step": round(ms_a, 4), "value": round(W * H / (ms_a * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
+            del alt
             # weak scaling beside it: every rank traces its own 1920x1080 dragon frame (64-byte records), no exchange
             Wf, Hf = 1920, 1080
             of = rt.frame_camera(box, Wf, Hf)
@@ -562,7 +625,9 @@ def main():
         if not sharded:
             step()                      # leaves frame 0's hits in hits_d for the spot check below
         elif world == 1:
-            fb_d.fill_(-1)              # wiped first: the spot check below must see THIS step's gather and scatter
+            for fb in fbs:
+                fb.fill_(-1)            # wiped first: the spot check below must see THIS step's gather and scatter
+            torch.cuda.synchronize()
             step()
             flush()
         torch.cuda.synchronize()
@@ -593,7 +658,7 @@ def main():
                 torch.cuda.synchronize()
                 got = src.cpu().numpy()
             else:
-                src = fb_d if sharded else hits_d
+                src = fb_last[0] if sharded else hits_d
                 got = src[torch.from_numpy(sel).cuda()].cpu().numpy()
             gid = got[:, 14 if full_out else 0].view(np.uint32)
             gt = got[:, 15 if full_out else 1]
@@ -616,7 +681,7 @@ def main():
             if sharded and pix:      # the framebuffer holds pixels: nothing to hold against the CPU's hits
                 gid, gt = oid, ot
             else:
-                src = fb_d if sharded else hits_d
+                src = fb_last[0] if sharded else hits_d
                 got = src[:len(all_rays)].cpu().numpy()
                 gid = got[:, 14 if full_out else 0].view(np.uint32)
                 gt = got[:, 15 if full_out else 1]
