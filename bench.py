@@ -505,13 +505,39 @@ def main():
         for more_rays in tables[1:]:   # records fetched: the mean over the frames the loop cycles through
             more = scene.count_fetches_device(more_rays.data_ptr(), n_count)
             cnt = {key: (max(cnt[key], more[key]) if key == "max_stack" else cnt[key] + more[key]) for key in cnt}
+        per_pass = None
+        if workload == "mirror5":
+            # The reflection passes trace rays the kernel derives from the records of the pass before
+            # (tracekernel.ck:227-233: reflect about the stored normal, step off the surface; a record that missed stays
+            # terminated).  The same rays are rebuilt here from each pass's input records and counted like any other rays.
+            per_pass = [{"pass": 0, "rays_traced": cnt["rays"], "node_records": cnt["nodes"], "tri_records": cnt["tris"]}]
+            scene.trace_pass(rays_d.data_ptr(), hits_d.data_ptr(), rgba_d.data_ptr(), n_local, cam, 0, stream)
+            torch.cuda.synchronize()
+            src, dst = hits_d, pong
+            for k in range(1, 5):
+                live = src[:, 14].view(torch.int32) != -1
+                d4, n4 = src[:, 4:8], src[:, 8:12]
+                s2 = 2.0 * (d4[:, 0] * n4[:, 0] + d4[:, 1] * n4[:, 1] + d4[:, 2] * n4[:, 2] + d4[:, 3] * n4[:, 3])
+                tab = torch.zeros_like(src)
+                tab[:, 0:3] = src[:, 0:3] + n4[:, 0:3] * 0.00001
+                tab[:, 3] = 1.0
+                tab[:, 4:7] = d4[:, 0:3] - s2[:, None] * n4[:, 0:3]
+                tab = tab[live].contiguous()
+                c = scene.count_fetches_device(tab.data_ptr(), len(tab)) if len(tab) else {"rays": 0, "nodes": 0, "tris": 0, "rays_hit": 0, "max_stack": 0, "leaves": 0}
+                per_pass.append({"pass": k, "rays_traced": c["rays"], "node_records": c["nodes"], "tri_records": c["tris"]})
+                cnt = {key: (max(cnt[key], c[key]) if key == "max_stack" else cnt[key] + c[key]) for key in cnt}
+                scene.trace_pass(src.data_ptr(), dst.data_ptr(), rgba_d.data_ptr(), n_local, cam, 1, stream)
+                torch.cuda.synchronize()
+                src, dst = dst, src
+                del tab
+            cnt["rays"] = 5 * n_local      # per ray RECORD of the five passes, terminated ones included (they fetch nothing)
         stride = max(1, len(rays_h) // 8192)
         cnt_cpu = scene.count_fetches(rays_h, stride)
         node_b = info["node4_bytes"] if width == 4 else info["node2_bytes"]
         n_node, n_tri = cnt["nodes"] / cnt["rays"], cnt["tris"] / cnt["rays"]
         in_b = 0 if (a.raygen == "device" and W and workload not in ("tiles4k", "mirror5")) else 64
         stream_b = in_b + out_b + (16 if workload == "mirror5" else 0)       # compulsory HBM bytes per ray
-        trav_b = 0.0 if workload == "mirror5" else n_node * node_b + n_tri * info["tri_bytes"]
+        trav_b = n_node * node_b + n_tri * info["tri_bytes"]
         if sharded:
             dev_ms = extra["trace_only_ms"]      # the roofline figures are the trace kernel's, not the exchange's
             if pix:
@@ -560,6 +586,7 @@ def main():
                             "tri_records_per_ray_cpu_sample": round(cnt_cpu["tris"] / max(1, cnt_cpu["rays"]), 3),
                             "traversal_GBs": round(trav_b * n_local / secs / 1e9, 1),
                             "hit_fraction": round(cnt["rays_hit"] / cnt["rays"], 4), "deepest_stack": cnt["max_stack"],
+                            "per_pass": per_pass,
                             "valu_lane_ops_per_ray": round(ops, 1),
                             "valu_lane_ops_frac_of_peak": round(ops * n_local / secs / (SIMDS * 32 * CLOCK_HZ), 4)},
         }
