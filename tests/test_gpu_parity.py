@@ -449,9 +449,21 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
     bvh = rt.BVH(mesh, "fixed")
     W, H = 640, 360
     rays = framed_primary(rt, bvh, W, H)
+    import torch
     scene = rt.Scene(mesh, bvh, device=gpu, width=2)
     base = scene.intersect(rays)
     compare(rt, oracle, mesh, rays, base, np.arange(0, len(rays), 61))
+    d_out = torch.empty((len(rays), 16), dtype=torch.float32, device="cuda")
+
+    def launch(table):
+        """rt_intersect_async on device buffers: the entry point whose launches follow the dispatch order and the cost
+        feedback (the host-pointer call cuts its input into chunks and launches those plainly)."""
+        d_in = torch.from_numpy(np.ascontiguousarray(table)).cuda()
+        d_out.fill_(-3.0)
+        scene.intersect_async(d_in.data_ptr(), len(table), d_out.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return d_out[:len(table)].cpu().numpy()
+
     settings = [
         dict(image_width=W, centre_first=0),
         dict(image_width=W, centre_first=1),
@@ -484,15 +496,16 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
         for k, v in {**defaults, **cfg}.items():
             scene.set_param(k, v)
         for rep in range(9):      # from launch 2 on in an order sorted from earlier launches' costs, re-sorted every period
-            out = scene.intersect(rays)
+            out = launch(rays)
             assert np.array_equal(bits(out), bits(base)), (cfg, rep)
+        assert np.array_equal(bits(scene.intersect(rays)), bits(base)), cfg      # and the host-pointer call
     # feedback state survives a change of shape and of rays between launches
     scene.set_param("feedback", 1)
     scene.set_param("image_width", W)
     for n in (len(rays), W * 8, len(rays), 1000, len(rays)):
         for rep in range(3):
             shifted = np.roll(rays[:n], rep * 17, axis=0)
-            out = scene.intersect(shifted)
+            out = launch(shifted)
             assert np.array_equal(bits(out), bits(np.roll(base[:n], rep * 17, axis=0))), (n, rep)
     scene.close()
 
