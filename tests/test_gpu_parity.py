@@ -141,6 +141,7 @@ def test_incoherent_rays_at_the_full_64_mi(rt, oracle, gpu):
         walked.append(np.stack([x.view(np.uint32) for x in oracle.closest_hit_bvh(mesh.verts, mesh.faces, bvh.nodes, part)], axis=1))
     sample = np.concatenate(sample)
     scene = rt.Scene(mesh, bvh, device=gpu, width=4)
+    scene.set_param("feedback", 1)
     try:
         hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
         scene.intersect_async(rays_d.data_ptr(), n, None, hits.data_ptr())
@@ -188,8 +189,16 @@ def test_every_ray_of_the_full_size_frames_matches_the_oracle(rt, oracle, gpu):
         rays = framed_primary(rt, bvh, W, H)
         s = rt.Scene(mesh, bvh, device=gpu, width=4)
         s.set_param("image_width", W)
-        s.set_param("feedback", 1)
-        hits = s.intersect(rays)
+        s.set_param("feedback", 1)       # bench.py's schedule: the fourth launch follows a cost-sorted order, 32 tiles split
+        import torch
+        d_rays = torch.from_numpy(rays).cuda()
+        d_hits = torch.empty_like(d_rays)
+        for rep in range(4):
+            d_hits.fill_(-3.0)
+            s.intersect_async(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        hits = d_hits.cpu().numpy()
+        del d_rays, d_hits
         s.close()
         ids, t, u, v = rt.hit_fields(hits)
         oid, ot, ou, ov = oracle.closest_hit_bvh(mesh.verts, mesh.faces, bvh.nodes, rays)
