@@ -127,8 +127,9 @@ int rt_scene_records(const rt_scene *s, int which, void *out, size_t capacity, s
  *   "image_width"    W > 0 declares that ray arrays whose length is a multiple of W are row-major W-wide images,
  *                    as the reference's 2-D NDRange is (render_client/img_main.cpp:457-461); each wave then
  *                    takes an 8x8 pixel tile.  0 = unstructured: each wave takes 64 consecutive records.
- *   "centre_first"   image mode: 1 dispatches the tiles nearest the image centre first, 0 in row order.
- *   "feedback"       1: launches record the traversal cost of each wave-sized work unit; small sort kernels on
+ *   "centre_first"   image mode, while no cost-sorted order exists (the first two launches of a shape, or "feedback"
+ *                    0): 1 dispatches the tiles nearest the image centre first, 0 in row order.
+ *   "feedback"       1 (default): launches record the traversal cost of each wave-sized work unit; small sort kernels on
  *                    a library-owned side stream turn that into a costliest-first dispatch order, which later
  *                    launches of the same shape (ray count, image width) on this scene use, from the launch
  *                    after next on.  A schedule only: every ray is traced on every launch.  Any change of shape starts over.

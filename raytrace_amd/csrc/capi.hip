@@ -130,7 +130,7 @@ struct rt_scene {
   int centre_first = 1;          // image mode: dispatch tiles nearest the image centre first
   mutable uint32_t *d_order = nullptr;   // cached dispatch order for (order_w, order_h)
   mutable uint32_t order_w = 0, order_h = 0;
-  int feedback = 0;              // reuse the previous launch's per-unit cost to start expensive units first
+  int feedback = 1;              // reuse the previous launch's per-unit cost to start expensive units first
   mutable uint32_t *d_fb_cost[2] = {nullptr, nullptr}, *d_fb_order[2] = {nullptr, nullptr}, *d_fb_bins = nullptr;
   mutable uint32_t fb_ntasks = 0, fb_n = 0, fb_img_w = 0;  // shape the feedback buffers describe
   mutable bool fb_sorted[2] = {false, false};               // d_fb_order[k] holds (or will hold, after ev_sort[k]) an order
