@@ -149,6 +149,7 @@ struct rt_scene {
   mutable std::vector<hipEvent_t> fb_left;      // pool of events, the first fb_left_used of them recorded since the last sort
   mutable size_t fb_left_used = 0;
   int waves_per_cu = 0;          // optional resident-wave cap per CU, held through the LDS stack size (0 = none)
+  int refill = 0;                // > 0: linear ray sets with compact hits go to the lane-refilling kernel; idle lanes that trigger a refill
   int split_units = 32;          // with a cost-sorted order: this many units, the costliest, are traced by four waves each
   int prio_permille = 0;         // with a cost-sorted order: this share (1/1000) of the leading dispatch slots runs at raised priority
   int lds_stack = 10;            // traversal-stack entries per lane kept in LDS; deeper entries spill to private memory
@@ -303,6 +304,20 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     const uint32_t groups = std::max(1u, static_cast<uint32_t>(s->waves_per_cu) / wpb);
     const uint32_t min_bytes = 160u * 1024u / (groups + 1u) + 1u, entry_bytes = 8u * block;
     a.stack_entries = std::max(a.stack_entries, (min_bytes + entry_bytes - 1u) / entry_bytes);
+  }
+  if (s->refill > 0 && !count && mode == rt::kModeIntersect && a.img_w == 0 && s->width == 4 && s->quant &&
+      a.n >= 65536u) {
+    // incoherent rays: a fixed grid of waves (as many as fit the chip at once) streams through the rays, every wave refilling
+    // its idle lanes from chunks it claims on a cursor word that this launch's stream zeroes first
+    int rc = CheckStack(s, a, block);
+    if (rc != RT_OK) return rc;
+    a.cursor = s->d_cursor + (s->next_cursor++ % kCursorSlots) * kCursorStride;
+    a.refill_min = static_cast<uint32_t>(s->refill);
+    RT_HIP(hipMemsetAsync(a.cursor, 0, sizeof(uint32_t), stream));
+    const uint32_t waves = static_cast<uint32_t>(s->num_cu) * 4u * rt::kRefillWavesPerSimd;
+    hipError_t e_ = rt::LaunchRefill(a, std::min((a.ntasks + wpb - 1u) / wpb, (waves + wpb - 1u) / wpb), block, stream);
+    if (e_ != hipSuccess) return Fail(RT_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(e_));
+    return RT_OK;
   }
   uint32_t grid = (a.ntasks + wpb - 1u) / wpb;   // one wave per work unit (more below if the costliest units are split)
   if (s->persistent && !count) {
@@ -783,6 +798,9 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "feedback_period") {
     if (value < 1 || value > 1024) return Fail(RT_ERR_INVALID, "feedback_period must be in 1..1024");
     s->feedback_period = value;
+  } else if (k == "refill") {
+    if (value < 0 || value > 64) return Fail(RT_ERR_INVALID, "refill must be in 0..64");
+    s->refill = value;
   } else if (k == "split_units") {
     if (value < 0 || value > 65536) return Fail(RT_ERR_INVALID, "split_units must be in 0..65536");
     s->split_units = value;

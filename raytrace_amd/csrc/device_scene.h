@@ -17,6 +17,14 @@ constexpr int kFbBuckets = 32;     // cost bins of the launch-to-launch feedback
 constexpr int kModeTrace = 1;      // full `trace` step: camera / reflection setup + pixel
 constexpr int kModePrimary = 2;    // rays of the reference's primary table, generated in the kernel (no ray array)
 constexpr uint32_t kDeepEntries = 56;   // traversal-stack entries per lane beyond the LDS part, in private memory
+#ifndef RT_REFILL_WAVES_PER_SIMD
+#define RT_REFILL_WAVES_PER_SIMD 6
+#endif
+#ifndef RT_REFILL_CHUNK
+#define RT_REFILL_CHUNK 128
+#endif
+constexpr uint32_t kRefillWavesPerSimd = RT_REFILL_WAVES_PER_SIMD;   // resident waves per SIMD of the lane-refilling kernel (80 VGPRs)
+constexpr uint32_t kRefillChunk = RT_REFILL_CHUNK;                   // consecutive rays a wave claims per atomic
 constexpr uint32_t kMinLdsEntries = 8;  // the output stage exchanges 64 x 64-byte records through the LDS part
 
 struct KernelArgs {
@@ -41,6 +49,7 @@ struct KernelArgs {
   uint32_t n;
   uint32_t ntasks;            // wave-sized work items: ceil(n/64), or the number of 8x8 tiles
   uint32_t split_units;       // the first this-many units of `order` are traced by four waves each, a quarter of the unit's rays per wave
+  uint32_t refill_min;        // RefillHitKernel: idle lanes of a wave that trigger handing out new rays
   uint32_t prio_slots;        // the first this-many dispatch slots run at raised issue priority (0 = none)
   uint32_t cost_radius;       // a unit's cost is also recorded for its neighbours within this many units (<= 3)
   uint32_t cost_share;        // ... scaled by this many 128ths
@@ -62,6 +71,9 @@ struct KernelArgs {
 // done (nullable): event signalled by the kernel's own completion (no separate record packet behind the launch)
 hipError_t LaunchClosestHit(const KernelArgs &a, int width, bool quant, int mode, bool count, uint32_t grid,
                             uint32_t block, hipStream_t stream, hipEvent_t done = nullptr);
+// Fixed grid of waves that stream through a linear ray set, refilling idle lanes (see RefillHitKernel); a.cursor must be a
+// zeroed word, the layout four-wide quantized.
+hipError_t LaunchRefill(const KernelArgs &a, uint32_t grid, uint32_t block, hipStream_t stream);
 // order[k] = k-th unit to start, costliest bin first, index order within a bin (three small launches on `stream`).
 // unit_cost must hold OrderPaddedUnits(nunits) entries and is zeroed after being read; bins is OrderBinWords(nunits) words
 // of work space.

@@ -618,6 +618,139 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
   }
 }
 
+// ---- incoherent rays: a wave's lanes take new rays as their old ones finish ------------------------------------
+// With one batch of 64 rays per wave, a wave of incoherent rays is as long as its longest ray and its other lanes idle
+// for the rest of it (AO-style rays: a quarter of the lanes busy per vector instruction).  Here a fixed grid of waves
+// streams through the ray set instead: whenever `refill_min` lanes of a wave are idle, the finished ones store their
+// compact hit and the idle ones take the next rays of the wave's current chunk (kRefillChunk consecutive records, claimed
+// with one wave-level atomic on a global cursor), set up and start at the root while the other lanes carry on where they
+// are.  Linear ray sets only (no image tiles).  Every wave leaves once the cursor has passed the last ray and
+// its lanes have finished -- an exit every wave reaches, whatever the rays are.
+
+// The 64-byte hit record of ray `idx` (tracekernel.ck:282-286 miss defaults, :373-399 hit), as the batch kernel's output
+// stage builds it, written straight from the lane: retiring lanes hold unrelated rays, there is no tile to exchange.
+__device__ __forceinline__ void StoreFullRecord(const KernelArgs &p, uint32_t idx, const Best &best, const float4 in_o, const float4 in_d)
+{
+  float4 out_o = in_o, out_n = in_d, out_d = in_d;
+  float out_u = 0.f, out_v = 0.f;
+  if (best.id != RT_MISS_ID) {
+    const rt_face f = p.faces[best.id];
+    const float u = best.u, v = best.v, w = 1.f - u - v;
+    const float4 v0 = *reinterpret_cast<const float4 *>(p.verts + f.s[0]);
+    const float4 v1 = *reinterpret_cast<const float4 *>(p.verts + f.s[1]);
+    const float4 v2 = *reinterpret_cast<const float4 *>(p.verts + f.s[2]);
+    out_o = make_float4(w * v0.x + u * v1.x + v * v2.x, w * v0.y + u * v1.y + v * v2.y, w * v0.z + u * v1.z + v * v2.z, 1.f);
+    float nx, ny, nz;
+    if (f.s[4] < p.nnormals && f.s[5] < p.nnormals && f.s[6] < p.nnormals) {
+      const float4 *np4 = reinterpret_cast<const float4 *>(p.normals);
+      const float4 n0 = np4[f.s[4]], n1 = np4[f.s[5]], n2 = np4[f.s[6]];
+      nx = u * n0.x + v * n1.x + w * n2.x;
+      ny = u * n0.y + v * n1.y + w * n2.y;
+      nz = u * n0.z + v * n1.z + w * n2.z;
+    } else {
+      const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
+      const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
+      nx = e1y * e2z - e1z * e2y; ny = e1z * e2x - e1x * e2z; nz = e1x * e2y - e1y * e2x;
+      const float len2 = nx * nx + ny * ny + nz * nz;
+      if (len2 > 0.f) {
+        const float inv_len = __builtin_amdgcn_rsqf(len2);
+        nx *= inv_len; ny *= inv_len; nz *= inv_len;
+      }
+    }
+    out_n = make_float4(nx, ny, nz, 0.f);
+    out_d = make_float4(in_d.x, in_d.y, in_d.z, 0.f);
+    out_u = u; out_v = v;
+  }
+  float4 *out = reinterpret_cast<float4 *>(p.hits + idx);
+  StoreStreamF4<true>(out, out_o);
+  StoreStreamF4<true>(out + 1, out_d);
+  StoreStreamF4<true>(out + 2, out_n);
+  StoreStreamF4<true>(out + 3, make_float4(out_u, out_v, __uint_as_float(best.id), best.t));
+}
+
+__global__ void __launch_bounds__(256, kRefillWavesPerSimd) RefillHitKernel(KernelArgs p)
+{
+  extern __shared__ uint2 lds_stack[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint2 *const wave_lds = lds_stack + wave * p.stack_entries * 64u;
+  uint2 deep[kDeepEntries];
+  RayCtx r;
+  RayCtxQ rq;
+  SetupRay(r, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, p.scale);   // defined values for lanes that never get a ray
+  SetupRayQ(rq, r, p.grid, p.scale);
+  Best best{kFltMax, 0.f, 0.f, RT_MISS_ID};
+  Stack st{(LdsWord *)(reinterpret_cast<uint32_t *>(wave_lds) + lane), p.stack_entries, 0u};
+  constexpr uint32_t kNoRay = 0xFFFFFFFFu;
+  uint32_t cur = kDone, idx = kNoRay;
+  float ray_ow = 0.f, ray_dw = 0.f;   // fourth components of the ray record: a missed ray's record passes them through
+  uint32_t c_next = 0, c_end = 0;   // the wave's chunk: records [c_next, c_end) are still to be handed out
+  bool exhausted = false;           // the global cursor has passed the last ray
+  for (;;) {
+    const unsigned long long idle = __ballot(cur == kDone);
+    const uint32_t nidle = __popcll(idle);
+    if (nidle == 64u || (!exhausted && nidle >= p.refill_min)) {
+      // claim, then start loading the new rays, then write the finished ones out (their lookups run under the ray loads),
+      // then set the new rays up
+      uint32_t take = 0;
+      if (!exhausted) {
+        if (c_next == c_end) {
+          uint32_t got = 0;
+          if (lane == 0) got = atomicAdd(p.cursor, kRefillChunk);
+          c_next = __builtin_amdgcn_readfirstlane(got);
+          if (c_next >= p.n) {
+            exhausted = true;
+            c_next = c_end = 0;
+          } else {
+            c_end = min(c_next + kRefillChunk, p.n);
+          }
+        }
+        take = min(nidle, c_end - c_next);
+      }
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
+      const bool getting = cur == kDone && rank < take;
+      const uint32_t new_idx = c_next + rank;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f), d = o;
+      if (getting) {
+        const float4 *rp = reinterpret_cast<const float4 *>(p.rays + new_idx);
+        o = LoadStreamF4<true>(rp);
+        d = LoadStreamF4<true>(rp + 1);
+      }
+      if (cur == kDone && idx != kNoRay) {
+        const bool hit = best.id != RT_MISS_ID;
+        if (p.hits16)
+          StoreStreamF4<true>(reinterpret_cast<float4 *>(p.hits16 + idx),
+                              make_float4(__uint_as_float(best.id), best.t, hit ? best.u : 0.f, hit ? best.v : 0.f));
+        if (p.hits)
+          StoreFullRecord(p, idx, best, make_float4(r.ox, r.oy, r.oz, ray_ow), make_float4(r.dx, r.dy, r.dz, ray_dw));
+        idx = kNoRay;
+      }
+      if (getting) {
+        idx = new_idx;
+        SetupRay(r, o.x, o.y, o.z, d.x, d.y, d.z, p.scale);
+        SetupRayQ(rq, r, p.grid, p.scale);
+        ray_ow = o.w; ray_dw = d.w;
+        best = Best{kFltMax, 0.f, 0.f, RT_MISS_ID};
+        st.sp = 0u;
+        cur = 0u;
+      }
+      c_next += take;
+      if (exhausted && __ballot(cur != kDone) == 0ull) return;
+    }
+    const bool inner = !(cur & kLeafBitDev);
+    const bool parked = !inner && cur != kDone;
+    const unsigned long long mi = __ballot(inner), ml = __ballot(parked);
+    const uint32_t ni = __popcll(mi), nl = __popcll(ml);
+    if (ni != 0u && nl * 100u < p.leaf_pct * (ni + nl)) {
+      if (inner) cur = NodeStep<4, true>(p, r, rq, cur, best.t, st, deep);
+    } else if (parked) {
+      uint32_t unused = 0;
+      LeafTest<false>(p, r, cur, best, unused);
+      cur = Pop(st, deep, best.t);
+    }
+  }
+}
+
 // Counting sort of work units by cost bin (cost / 8, capped), costliest bin first, ascending unit index inside a bin so
 // neighbouring units stay neighbours.  Three small launches of ONE-WAVE workgroups: the sort runs on a side stream beside a
 // trace launch that refills every wave slot the moment it frees, and a workgroup of several waves, which needs that many
@@ -842,6 +975,19 @@ hipError_t LaunchClosestHit(const KernelArgs &args, int width, bool quant, int m
                  : LaunchLayout<4, false>(a, mode, count, grid, block, lds, stream, done);
   return quant ? LaunchLayout<2, true>(a, mode, count, grid, block, lds, stream, done)
                : LaunchLayout<2, false>(a, mode, count, grid, block, lds, stream, done);
+}
+
+hipError_t LaunchRefill(const KernelArgs &a, uint32_t grid, uint32_t block, hipStream_t stream)
+{
+  (void)hipGetLastError();
+  const size_t lds = static_cast<size_t>(a.stack_entries) * 8u * block;
+  if (lds > 64u * 1024u) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&RefillHitKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(RefillHitKernel, dim3(grid), dim3(block), lds, stream, a);
+  return hipGetLastError();
 }
 
 uint32_t OrderPaddedUnits(uint32_t nunits) { return (nunits + kOrderChunk - 1u) / kOrderChunk * kOrderChunk; }

@@ -121,6 +121,47 @@ def test_incoherent_rays_match_oracle(rt, oracle, gpu):
         scene.close()
 
 
+def test_lane_refill_kernel_equals_the_batch_kernel_and_the_oracle(rt, oracle, gpu):
+    """"refill" > 0 sends linear ray sets to the kernel whose waves stream through the rays and hand new ones to lanes
+    as they finish.  Which rays share a wave, and when, must not show in any record: 64-byte records and 16-byte hits of
+    1 048 576 + 777 incoherent rays equal the batch kernel's bit for bit for three thresholds, and every hit equals the
+    oracle's tree walk."""
+    import torch
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny_big.obj"), "tolerant")
+    bvh = rt.BVH(mesh, "fixed")
+    n = (1 << 20) + 777                      # not a multiple of the chunk a wave claims, nor of 64
+    rays = rt.ao_rays(mesh, bvh.root_box, 4321, 0, n)
+    d_rays = torch.from_numpy(rays).cuda()
+    scene = rt.Scene(mesh, bvh, device=gpu, width=4)
+    stream = torch.cuda.current_stream().cuda_stream
+    full = torch.empty((n, 16), dtype=torch.float32, device="cuda")
+    compact = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    scene.set_param("refill", 0)
+    scene.intersect_async(d_rays.data_ptr(), n, full.data_ptr(), compact.data_ptr(), stream)
+    torch.cuda.synchronize()
+    want_full, want_compact = full.clone(), compact.clone()
+    oid, ot, ou, ov = oracle.closest_hit_bvh(mesh.verts, mesh.faces, bvh.nodes, rays)
+    got = want_compact.cpu().numpy()
+    h = oid != rt.MISS_ID
+    assert 0.02 * n < h.sum() < 0.9 * n
+    assert np.array_equal(got[:, 0].view(np.uint32), oid)
+    for k, want in ((1, ot), (2, ou), (3, ov)):
+        assert np.array_equal(bits(got[h, k]), bits(want[h]))
+    for threshold in (1, 32, 64):
+        scene.set_param("refill", threshold)
+        for outs in ((full, compact), (full, None), (None, compact)):
+            full.fill_(-9.0)
+            compact.fill_(-9.0)
+            scene.intersect_async(d_rays.data_ptr(), n, outs[0].data_ptr() if outs[0] is not None else None,
+                                  outs[1].data_ptr() if outs[1] is not None else None, stream)
+            torch.cuda.synchronize()
+            if outs[0] is not None:
+                assert torch.equal(full.view(torch.int32), want_full.view(torch.int32)), threshold
+            if outs[1] is not None:
+                assert torch.equal(compact.view(torch.int32), want_compact.view(torch.int32)), threshold
+    scene.close()
+
+
 def test_incoherent_rays_at_the_full_64_mi(rt, oracle, gpu):
     """The divergence-stress configuration at its stated size: 64 Mi seeded AO-style rays through bunny_big in one
     call (4.3 GB of ray records resident in HBM, 1 GB of compact hits).  Every one of the 67 108 864 hits is compared
