@@ -179,6 +179,11 @@ def main():
         return sc
 
     scene = make_scene(bvh)
+    refill_on = False
+    if workload == "ao" and width == 4 and not any(kv.startswith("refill=") for kv in a.param):
+        # incoherent rays: the kernel whose waves stream through the rays and refill their idle lanes (40 idle lanes trigger it)
+        scene.set_param("refill", 40)
+    refill_on = workload == "ao" and width == 4 and not any(kv == "refill=0" for kv in a.param)
     info = scene.info()
     box = bvh.root_box
     stream = torch.cuda.current_stream().cuda_stream
@@ -543,7 +548,7 @@ def main():
             if pix:
                 out_b = 16                       # the RGBA32F pixel the trace step writes (packed to 4 bytes by a second kernel)
         secs = dev_ms * 1e-3
-        key = f"{workload}/{a.bvh}/w{width}/out{out_b}/{a.raygen}"
+        key = f"{workload}/{a.bvh}/w{width}/out{out_b}/{a.raygen}" + ("/refill" if refill_on else "")
         pmc_table, pmc_src = newest_profile_table("pmc_table.json")
         pmc = pmc_table.get(key) if world == 1 else None
         peaks, _ = newest_profile_table("l2_gather_peak.json")
@@ -577,7 +582,7 @@ def main():
             "bound": bound, "achieved": res[bound]["achieved"], "peak": res[bound]["peak"], "unit": res[bound]["unit"],
             "frac": res[bound]["frac"], "traffic": traffic, "traffic_unit": "GB per launch, HBM side (2 x FETCH_SIZE + WRITE_SIZE)",
             "resources": res, "counters_from": pmc_src if pmc else None, "counters_key": key,
-            "kernel": "ClosestHitKernel", "kernel_ms": round(dev_ms, 4),
+            "kernel": "RefillHitKernel" if refill_on else "ClosestHitKernel", "kernel_ms": round(dev_ms, 4),
             # the algorithmic traversal figure, never compared with the HBM peak: most of it is served by L1/L2
             "algorithmic": {"bytes_per_ray": round(stream_b + trav_b, 1), "stream_bytes_per_ray": stream_b,
                             "node_records_per_ray": round(n_node, 3), "tri_records_per_ray": round(n_tri, 3),
@@ -740,8 +745,9 @@ def main():
                        "hit_record": "64B RayIntersection" if out_b == 64 else ("16B RGBA32F pixel -> 4B BGRA" if (sharded and pix) else "16B {id,t,u,v}"),
                        "frames": frames,
                        "rays": "RayIntersection table resident in HBM" if in_b else "generated in the kernel (rt_trace_primary)",
-                       "dispatch_order": "costliest work unit first, from the costs a launch 2 to 10 launches earlier measured (re-sorted every 8th launch)" if a.feedback
-                       else "image centre first",
+                       "dispatch_order": ("a fixed grid of waves streams through the rays in index order, lanes take new rays as they finish (refill)" if refill_on
+                                          else "costliest work unit first, from the costs a launch 2 to 10 launches earlier measured (re-sorted every 8th launch)"
+                                          if a.feedback else "image centre first"),
                        "parallelism": f"{world} x one process per GPU, " + ("cost-balanced image squares + RCCL gather (beside the next frame's trace) + device scatter"
                                                                             if sharded else "frame-parallel")},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_bvh": cpu_bvh, "same_launch_on_sah_tree": other, "two_frames_in_flight": overlapped,

@@ -140,6 +140,12 @@ int rt_scene_records(const rt_scene *s, int which, void *out, size_t capacity, s
  *                    by share/128, for the units within `radius` of it (tiles in both image directions), so
  *                    that the order still starts the right tiles first when the camera moved between the
  *                    launches.  Defaults 1 and 96; 0 and anything = exact per-unit costs, best for repeated rays.
+ *   "refill"         0 (default) or 1..64, for ray sets without an image hint of at least 65 536 rays on the four-wide
+ *                    quantized layout: a fixed grid of waves streams through the rays in index order, and whenever
+ *                    this many lanes of a wave are idle they store their finished hits and take the wave's next
+ *                    rays, while the other lanes carry on.  For incoherent rays (AO-style: +34 % with 64-byte
+ *                    records, +50 % with 16-byte hits at 40); coherent rays lose their shared paths with it (a
+ *                    1080p primary table without the image hint runs 2.4x slower), hence off unless asked for.
  *   "split_units"    0..65536 (default 32, with "feedback"): a launch ends with its longest wave, and a wave is as
  *                    long as the traversal steps its rays need between them; this many units at the head of the
  *                    costliest-first order are traced by four waves each (4x4 pixels or 16 records per wave) instead

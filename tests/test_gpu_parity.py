@@ -166,7 +166,8 @@ def test_incoherent_rays_at_the_full_64_mi(rt, oracle, gpu):
     """The divergence-stress configuration at its stated size: 64 Mi seeded AO-style rays through bunny_big in one
     call (4.3 GB of ray records resident in HBM, 1 GB of compact hits).  Every one of the 67 108 864 hits is compared
     (ids and the bits of t, u, v) with the oracle's tree walk, slice by slice; a sub-sample spread over the whole set is
-    also held against the brute-force loop, and three more launches and the two-wide layout must return the same bits."""
+    also held against the brute-force loop, and three more launches, the lane-refilling kernel and the two-wide layout
+    must return the same bits."""
     import torch
     mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny_big.obj"), "tolerant")
     bvh = rt.BVH(mesh, "fixed")
@@ -204,6 +205,12 @@ def test_incoherent_rays_at_the_full_64_mi(rt, oracle, gpu):
             scene.intersect_async(rays_d.data_ptr(), n, None, again.data_ptr())
             torch.cuda.synchronize()
             assert torch.equal(again.view(torch.int32), hits.view(torch.int32)), rep
+        scene.set_param("refill", 40)                # the lane-refilling kernel: which rays share a wave must not show
+        again.zero_()
+        scene.intersect_async(rays_d.data_ptr(), n, None, again.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(again.view(torch.int32), hits.view(torch.int32))
+        scene.set_param("refill", 0)
         scene.set_param("width", 2)
         scene.intersect_async(rays_d.data_ptr(), piece, None, again.data_ptr())
         torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condenses a tools/profile_gpu.sh output directory into a short text summary:
 per-kernel time statistics from the kernel trace and per-launch means of every PMC counter for
-the closest-hit kernel."""
+the trace kernel that took most of the run (the batch kernel, or the lane-refilling one)."""
 import csv
 import glob
 import os
@@ -22,6 +22,7 @@ print("== kernel trace (per kernel: launches, mean/min/max duration in us) ==")
 dur = defaultdict(list)
 for r in rows("trace/**/*kernel_trace.csv"):
     dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+KERNEL = max(("ClosestHitKernel", "RefillHitKernel"), key=lambda name: sum(sum(v) for k, v in dur.items() if name in k))
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     print(f"{len(v):6d}  mean {sum(v)/len(v):10.2f}  min {min(v):10.2f}  max {max(v):10.2f}  total {sum(v)/1e3:9.2f} ms  {k[:110]}")
 for r in rows("trace/**/*kernel_trace.csv"):
