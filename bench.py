@@ -615,6 +615,22 @@ def main():
             other = {"bvh": "sah", "ms_per_step": round(sms, 4), "value": round(n_local / (sms * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
             scene_s.close()
 
+        # the same frames with the rays generated in the kernel (rt_trace_primary: no 64-byte ray record is read)
+        in_kernel = None
+        if world == 1 and W and not sharded and workload in ("dragon1080", "bunny1080", "dragon4k") and a.raygen == "table" and not a.no_compare:
+            k_no = [0]
+
+            def step_g():
+                k_no[0] += 1
+                scene.trace_primary(W, H, origins[k_no[0] % len(origins)], hits_d.data_ptr() if full_out else None,
+                                    None if full_out else hits_d.data_ptr(), stream)
+            for _ in range(a.warmup):
+                step_g()
+            w_g, _ = timed(None, a.steps, step_g)
+            gms = w_g * 1e3 / max(1, a.steps)
+            in_kernel = {"ms_per_step": round(gms, 4), "value": round(n_local / (gms * 1e-3) / 1e6, 1), "unit": "Mrays/s",
+                         "what": "rt_trace_primary: the same camera rays computed in the kernel, bit-identical to the table, instead of read from HBM"}
+
         # the same steps issued alternately on two streams (two frames in flight, each with its own hit buffer): the tail of
         # one launch overlaps the head of the next.  Reported beside `value`, never as it: launches overlap, so there is no
         # per-launch duration to hold against a profile.
@@ -750,7 +766,7 @@ def main():
                                           if a.feedback else "image centre first"),
                        "parallelism": f"{world} x one process per GPU, " + ("cost-balanced image squares + RCCL gather (beside the next frame's trace) + device scatter"
                                                                             if sharded else "frame-parallel")},
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_bvh": cpu_bvh, "same_launch_on_sah_tree": other, "two_frames_in_flight": overlapped,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_bvh": cpu_bvh, "same_launch_on_sah_tree": other, "rays_generated_in_kernel": in_kernel, "two_frames_in_flight": overlapped,
             "host_pointer_call": host_call,
         }
         line.update(extra)
