@@ -89,21 +89,28 @@ constexpr int kMaxDevices = 64;
 struct StaticState {
   uint32_t *ptr = nullptr;      // device address of `scratch` on this GPU
   uint32_t ntasks = 0, n = 0, img_w = 0;   // shape the tables currently describe
-  bool order_valid = false;     // the order half holds a schedule for that shape
+  uint64_t scene_id = 0;        // ... and the scene whose costs they hold (0 = none)
+  bool order_valid = false;     // the order half holds a schedule for that shape and scene
   uint32_t since_sort = 0;      // calls since the last one that recorded costs and was followed by a sort
+  hipStream_t last_stream = nullptr;   // stream of the previous call
+  bool have_last = false;
+  hipEvent_t ev_left = nullptr; // recorded on the stream being left when calls change stream (created with the address lookup)
 };
 StaticState g_static[kMaxDevices];
-std::mutex g_static_mutex;   // guards the one-time address lookup only
+std::mutex g_static_mutex;   // guards the table state: the lookup, and every rt_intersect_static call from its first read of the
+                             // state to its last enqueue
+std::atomic<uint64_t> g_next_scene_id{1};
 
-// Caller holds the device current.
+// Caller holds the device current and g_static_mutex.
 int StaticScratch(int device, StaticState **out)
 {
   if (device < 0 || device >= kMaxDevices) return Fail(RT_ERR_DEVICE, "device ordinal beyond the allocation-free entry point's table");
   StaticState &st = g_static[device];
-  std::lock_guard<std::mutex> lock(g_static_mutex);
   if (!st.ptr) {
     void *p = nullptr;
     RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    // the event that orders calls on different streams is made here, where allocating is allowed (rt_scene_create)
+    if (!st.ev_left) RT_HIP(hipEventCreateWithFlags(&st.ev_left, hipEventDisableTiming));
     st.ptr = static_cast<uint32_t *>(p);
   }
   *out = &st;
@@ -122,6 +129,7 @@ struct rt_bvh {
 };
 
 struct rt_scene {
+  uint64_t id = g_next_scene_id.fetch_add(1);   // never reused: tells scenes apart where a pointer could come back
   int device = 0;
   int num_cu = 256;
   int width = 2;
@@ -138,6 +146,7 @@ struct rt_scene {
   mutable uint32_t fb_launch = 0;
   mutable uint32_t fb_since_sort = 0;                       // launches since the last one that recorded costs
   mutable int fb_cur = 0, fb_newest = 0;                    // set the launches record into; set of the sort enqueued last
+  int side_priority = 0;                                    // 1: the order-building side stream is created at the highest stream priority
   int feedback_period = 8;                                  // every this-many launches one records its costs and a sort follows it
   mutable hipStream_t side = nullptr;                       // the order-building kernel runs here, beside the next trace
   mutable hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_sort[2] = {nullptr, nullptr};
@@ -178,6 +187,7 @@ struct rt_scene {
   mutable void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
   mutable hipStream_t st_h2d = nullptr, st_trace = nullptr, st_d2h = nullptr;
   mutable hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_trace[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
+  mutable hipEvent_t ev_entry = nullptr;   // marks what the caller's null stream held when a mixed host/device call came in
 };
 
 namespace {
@@ -258,18 +268,19 @@ int ResetFeedback(const rt_scene *s)
   return RT_OK;
 }
 
-// Enqueues one launch over at most 2^30 rays.
 // The traversal stack must cover the tree's worst case (LDS part + private part), and the LDS part of one
-// workgroup must fit a CU.
-int CheckStack(const rt_scene *s, const rt::KernelArgs &a, uint32_t block)
+// workgroup must fit a CU.  May raise a.stack_entries.
+int CheckStack(const rt_scene *s, rt::KernelArgs &a, uint32_t block)
 {
   const uint32_t need = static_cast<uint32_t>(s->width == 4 ? s->flat.stack4 : s->flat.stack2);
-  if (need > a.stack_entries + rt::kDeepEntries)
-    return Fail(RT_ERR_INVALID, "bvh too deep for the traversal stack: " + std::to_string(need) + " entries needed, " +
-                                    std::to_string(a.stack_entries + rt::kDeepEntries) + " available");
+  // a tree deeper than the configured LDS part plus the private part can hold (a caller's degenerate tree, long chains of
+  // fallback splits): grow the LDS part to fit, as far as a CU's LDS allows
+  if (need > a.stack_entries + rt::kDeepEntries) a.stack_entries = need - rt::kDeepEntries;
   if (static_cast<size_t>(a.stack_entries) * 8u * block > 160u * 1024u)
     return Fail(RT_ERR_INVALID, "traversal stack of " + std::to_string(a.stack_entries) + " LDS entries x " + std::to_string(block) +
-                                    " threads exceeds a CU's 160 KB of LDS (lower waves_per_cu / lds_stack / extra_stack)");
+                                    " threads exceeds a CU's 160 KB of LDS: the tree needs " + std::to_string(need) + " stack entries per ray, " +
+                                    std::to_string(rt::kDeepEntries) + " of which live in private memory (a shallower tree, a smaller "
+                                    "\"block_threads\", or lower \"waves_per_cu\" / \"lds_stack\" / \"extra_stack\" settings fit)");
   return RT_OK;
 }
 
@@ -340,9 +351,21 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
         RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_order[k]), static_cast<size_t>(a.ntasks) * sizeof(uint32_t)));
       }
       if (!s->side) {
-        // default priority: a high-priority side stream whose sort waits on the trace launch of a null-stream caller was
-        // seen to stop both streams for good
-        RT_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        // The side stream must be NON-BLOCKING.  A stream created with default flags (which is what
+        // hipStreamCreateWithPriority(&q, 0, prio) gives) synchronises implicitly with the legacy null stream: a trace launch
+        // of a null-stream caller then waits for everything the side stream holds, and the side stream's head waits for that
+        // launch's stop event -- a cycle that stops both for good.  hipStreamNonBlocking takes the stream out of the null
+        // stream's implicit barrier, with or without a priority ("side_priority").
+        if (s->side_priority) {
+          int least = 0, greatest = 0;
+          RT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+          RT_HIP(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, greatest));
+        } else {
+          RT_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        }
+        unsigned side_flags = 0;
+        RT_HIP(hipStreamGetFlags(s->side, &side_flags));
+        if (!(side_flags & hipStreamNonBlocking)) return Fail(RT_ERR_DEVICE, "internal: the order-building stream is not non-blocking");
         for (int k = 0; k < 2; ++k) {
           RT_HIP(hipEventCreateWithFlags(&s->ev_main[k], hipEventDisableTiming));
           RT_HIP(hipEventCreateWithFlags(&s->ev_sort[k], hipEventDisableTiming));
@@ -657,6 +680,7 @@ int rt_scene_create(const rt_vec3 *verts, size_t nverts, const rt_face *faces, s
   if (rc == RT_OK && hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cu = prop.multiProcessorCount;
   if (rc == RT_OK) {   // look the fixed tables of rt_intersect_static up now, so that its calls have nothing left to set up
     StaticState *st = nullptr;
+    std::lock_guard<std::mutex> lock(g_static_mutex);
     rc = StaticScratch(device, &st);
   }
   if (rc == RT_OK) rc = Upload(&s->d_verts, verts, nverts * sizeof(rt_vec3));
@@ -731,6 +755,7 @@ void rt_scene_destroy(rt_scene *s)
     if (s->pin_out[k]) (void)hipHostFree(s->pin_out[k]);
     if (s->ev_h2d[k]) { (void)hipEventDestroy(s->ev_h2d[k]); (void)hipEventDestroy(s->ev_trace[k]); (void)hipEventDestroy(s->ev_d2h[k]); }
   }
+  if (s->ev_entry) (void)hipEventDestroy(s->ev_entry);
   if (s->st_h2d) { (void)hipStreamDestroy(s->st_h2d); (void)hipStreamDestroy(s->st_trace); (void)hipStreamDestroy(s->st_d2h); }
   delete s;
 }
@@ -798,6 +823,17 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "feedback_period") {
     if (value < 1 || value > 1024) return Fail(RT_ERR_INVALID, "feedback_period must be in 1..1024");
     s->feedback_period = value;
+  } else if (k == "side_priority") {
+    if (value < 0 || value > 1) return Fail(RT_ERR_INVALID, "side_priority must be 0 or 1");
+    if (s->side && value != s->side_priority) {   // the stream is made on first use: drop it so that the next launch makes the other kind
+      DeviceGuard guard(s->device);
+      int rc = ResetFeedback(s);
+      if (rc != RT_OK) return rc;
+      (void)hipStreamDestroy(s->side);
+      for (int j = 0; j < 2; ++j) { (void)hipEventDestroy(s->ev_main[j]); (void)hipEventDestroy(s->ev_sort[j]); s->ev_main[j] = s->ev_sort[j] = nullptr; }
+      s->side = nullptr;
+    }
+    s->side_priority = value;
   } else if (k == "refill") {
     if (value < 0 || value > 64) return Fail(RT_ERR_INVALID, "refill must be in 0..64");
     s->refill = value;
@@ -867,6 +903,9 @@ int rt_intersect_static(const rt_scene *s, const void *rays_dev, size_t n, void 
                                     std::to_string(n) + " given); split the call or use rt_intersect_async");
   DeviceGuard guard(s->device);
   if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  // One call at a time per process touches the table state and enqueues against it: two threads, two scenes or two streams
+  // can no longer interleave a half-updated state with a launch (the enqueues are short; the GPU work is not waited for).
+  std::lock_guard<std::mutex> lock(g_static_mutex);
   StaticState *st = nullptr;
   int rc = StaticScratch(s->device, &st);
   if (rc != RT_OK) return rc;
@@ -883,13 +922,22 @@ int rt_intersect_static(const rt_scene *s, const void *rays_dev, size_t n, void 
                                     std::to_string(kStaticMaxUnits) + ")");
   rc = CheckStack(s, a, 64u);
   if (rc != RT_OK) return rc;
+  // Calls on another stream than the one before: what the stream being left still has enqueued (a trace that reads the
+  // order half, a sort that rewrites both halves) must be done before this stream touches the tables.
+  if (st->have_last && st->last_stream != q) {
+    RT_HIP(hipEventRecord(st->ev_left, st->last_stream));
+    RT_HIP(hipStreamWaitEvent(q, st->ev_left, 0));
+  }
+  st->last_stream = q;
+  st->have_last = true;
   uint32_t *cost = st->ptr, *order = st->ptr + kStaticMaxUnits, *bins = st->ptr + 2u * kStaticMaxUnits;
   const size_t padded = rt::OrderPaddedUnits(a.ntasks);   // <= kStaticMaxUnits, and its bin counters <= kStaticBinWords
-  if (st->ntasks != a.ntasks || st->n != a.n || st->img_w != a.img_w) {
-    // the array keeps the previous call's contents: a new shape starts from zero costs and no order
+  if (st->ntasks != a.ntasks || st->n != a.n || st->img_w != a.img_w || st->scene_id != s->id) {
+    // the array keeps the previous call's contents: a new shape, or another scene, starts from zero costs and no order
     RT_HIP(hipMemsetAsync(cost, 0, padded * sizeof(uint32_t), q));
-    st->ntasks = a.ntasks; st->n = a.n; st->img_w = a.img_w;
+    st->ntasks = a.ntasks; st->n = a.n; st->img_w = a.img_w; st->scene_id = s->id;
     st->order_valid = false;
+    st->since_sort = 0;
   }
   // as in rt_intersect_async: only every feedback_period-th call (and the first of a shape) records costs and re-sorts
   const bool sort_now = !st->order_valid || st->since_sort + 1u >= static_cast<uint32_t>(s->feedback_period);
@@ -999,6 +1047,7 @@ int EnsureHostPipeline(const rt_scene *s)
     RT_HIP(hipEventCreateWithFlags(&s->ev_trace[k], hipEventDisableTiming));
     RT_HIP(hipEventCreateWithFlags(&s->ev_d2h[k], hipEventDisableTiming));
   }
+  RT_HIP(hipEventCreateWithFlags(&s->ev_entry, hipEventDisableTiming));
   RT_HIP(hipStreamCreateWithFlags(&s->st_trace, hipStreamNonBlocking));
   RT_HIP(hipStreamCreateWithFlags(&s->st_d2h, hipStreamNonBlocking));
   RT_HIP(hipStreamCreateWithFlags(&s->st_h2d, hipStreamNonBlocking));   // last: its presence marks the set complete
@@ -1075,6 +1124,15 @@ int ray_scene_intersection(const void *rays, size_t n, const rt_scene *scene, vo
     if (e_ != hipSuccess) return finish(FailHip(e_, #call));      \
   } while (0)
 
+  if (in_dev || out_dev) {
+    // A device-side buffer belongs to the caller's in-order null stream (the reference's one in-order queue,
+    // render_client/img_main.cpp:313): rays that a kernel or copy enqueued there is still producing, hits that earlier work
+    // there still reads.  The pipeline's streams do not synchronise with the null stream by themselves, so they wait for
+    // everything it held when the call came in; the call returns only after its own streams have drained.
+    RT_PIPE(hipEventRecord(s->ev_entry, nullptr));
+    RT_PIPE(hipStreamWaitEvent(s->st_h2d, s->ev_entry, 0));
+    RT_PIPE(hipStreamWaitEvent(s->st_trace, s->ev_entry, 0));
+  }
   CopyMate in_mate;
   for (size_t c = 0; c < nchunks; ++c) {
     const int slot = static_cast<int>(c & 1);

@@ -421,6 +421,99 @@ def test_device_pointers_streams_and_errors(rt, oracle, gpu):
                                   gpu, 3, C.byref(h)) == -1
 
 
+def test_mixed_host_device_calls_are_ordered_behind_the_null_stream(rt, oracle, gpu):
+    """ray_scene_intersection keeps the reference's in-order queue semantics (one in-order queue, clFinish per pass:
+    render_client/img_main.cpp:313,480) when one side of the call is a device buffer: device rays that earlier null-stream
+    work is still producing are read only after it, and device hits that earlier null-stream work still writes are not
+    overtaken.  Both directions, with a few milliseconds of null-stream work enqueued right before the call."""
+    import ctypes as C
+    import torch
+    mesh, bvh, scene = rt.load_scene("teapot.obj", device=gpu, width=4)
+    rays = framed_primary(rt, bvh, 512, 384)
+    want = scene.intersect(rays)
+    n = len(rays)
+    src = torch.from_numpy(rays).cuda()
+    ballast = torch.randn((4096, 4096), device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(3):
+        # device rays -> host hits: the rays reach their buffer at the END of a long null-stream chain
+        d_rays = torch.zeros_like(src)
+        hits_h = np.full_like(rays, -3.0)
+        for _ in range(6):
+            ballast = ballast @ ballast * 1e-4
+        d_rays.copy_(src, non_blocking=True)
+        assert rt.lib.ray_scene_intersection(C.c_void_p(d_rays.data_ptr()), n, scene._h, C.c_void_p(hits_h.ctypes.data)) == 0
+        assert np.array_equal(bits(hits_h), bits(want)), rep
+        # host rays -> device hits: a fill of the hit buffer sits at the end of the same kind of chain
+        d_hits = torch.empty((n, 16), dtype=torch.float32, device="cuda")
+        for _ in range(6):
+            ballast = ballast @ ballast * 1e-4
+        d_hits.fill_(-5.0)
+        assert rt.lib.ray_scene_intersection(C.c_void_p(rays.ctypes.data), n, scene._h, C.c_void_p(d_hits.data_ptr())) == 0
+        assert np.array_equal(bits(d_hits.cpu().numpy()), bits(want)), rep
+    scene.close()
+
+
+def test_a_tree_deeper_than_the_default_stack_grows_the_lds_part(rt, oracle, gpu):
+    """A caller's degenerate tree: a two-wide chain of 90 inner nodes, every one holding a one-triangle leaf and the rest of
+    the chain.  Its worst-case stack (91 two-wide, 3 * depth + 1 four-wide) is beyond the default LDS part plus the private
+    part; the launch grows the LDS part instead of failing, and every hit equals the brute-force oracle."""
+    D = 91   # triangles = leaves; D - 1 inner nodes
+    verts = np.zeros((3 * D, 4), np.float32)
+    faces = np.zeros((D, 8), np.uint32)
+    for i in range(D):
+        x = 2.0 * i
+        verts[3 * i:3 * i + 3, :3] = [[x, 0, 0], [x + 1, 0, 0], [x, 1, 0.25]]
+        verts[3 * i:3 * i + 3, 3] = 1.0
+        faces[i, :3] = [3 * i, 3 * i + 1, 3 * i + 2]
+    mesh = rt.Mesh.from_arrays(verts, faces)
+    nodes = np.zeros((2 * D - 1, 20), np.uint32)
+
+    def box_of(lo_tri, hi_tri):
+        v = verts[3 * lo_tri:3 * hi_tri + 3, :3]
+        lo, hi = v.min(axis=0) - 0.01, v.max(axis=0) + 0.01
+        return np.concatenate([lo, [1.0], hi, [1.0]]).astype(np.float32).view(np.uint32)
+
+    # node 2k = inner over triangles k..D-1 (children: leaf 2k+1 with triangle k, inner 2k+2), last node = leaf D-1
+    for k in range(D - 1):
+        inner, leaf, rest = 2 * k, 2 * k + 1, 2 * k + 2
+        nodes[inner, 4:6] = [leaf, rest]
+        nodes[inner, 8:16] = box_of(k, D - 1)
+        nodes[inner, 16] = 0          # RT_BVH_INNER
+        nodes[inner, 17] = max(0, inner - 2)
+        nodes[leaf, 0] = k
+        nodes[leaf, 4] = 1            # leaf.count
+        nodes[leaf, 8:16] = box_of(k, k)
+        nodes[leaf, 16] = 1           # RT_BVH_LEAF
+        nodes[leaf, 17] = inner
+    last = 2 * D - 2
+    nodes[last, 0] = D - 1
+    nodes[last, 4] = 1
+    nodes[last, 8:16] = box_of(D - 1, D - 1)
+    nodes[last, 16] = 1
+    nodes[last, 17] = last - 2
+    rng = np.random.default_rng(5)
+    n = 4096
+    rays = np.zeros((n, 16), np.float32)
+    rays[:, 0] = rng.uniform(-1, 2 * D + 1, n)
+    rays[:, 1] = rng.uniform(-0.5, 1.5, n)
+    rays[:, 2] = -3.0
+    rays[:, 3] = 1.0
+    d = np.stack([rng.uniform(-0.8, 0.8, n), rng.uniform(-0.1, 0.1, n), np.ones(n)], axis=1)
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    oid, ot, ou, ov = oracle.closest_hit(mesh.verts, mesh.faces, rays)
+    assert (oid != rt.MISS_ID).sum() > 100
+    for width in (2, 4):
+        scene = rt.Scene(mesh, nodes, device=gpu, width=width)
+        scene.set_param("width", width)
+        got = scene.intersect(rays)
+        scene.close()
+        ids, t, u, v = rt.hit_fields(got)
+        hit = oid != rt.MISS_ID
+        assert np.array_equal(ids, oid), width
+        assert np.array_equal(bits(t[hit]), bits(ot[hit])) and np.array_equal(bits(u[hit]), bits(ou[hit])), width
+
+
 def test_one_scene_on_several_streams_with_the_cost_feedback(rt, gpu):
     """Launches of one scene may go to any streams.  With the cost feedback on, the sort that rewrites a dispatch-order
     table must wait for readers on every stream, not only the one it follows: sixty launches dealt to three streams
