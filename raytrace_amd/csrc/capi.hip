@@ -159,7 +159,8 @@ struct rt_scene {
   mutable size_t fb_left_used = 0;
   int waves_per_cu = 0;          // optional resident-wave cap per CU, held through the LDS stack size (0 = none)
   int refill = 0;                // > 0: linear ray sets with compact hits go to the lane-refilling kernel; idle lanes that trigger a refill
-  int split_units = 32;          // with a cost-sorted order: this many units, the costliest, are traced by four waves each
+  int split_coop = 1;            // the quarter waves of split units work four lanes per ray (one child box / one triangle per lane)
+  int split_units = 128;         // with a cost-sorted order: this many units, the costliest, are traced by four waves each
   int prio_permille = 0;         // with a cost-sorted order: this share (1/1000) of the leading dispatch slots runs at raised priority
   int lds_stack = 10;            // traversal-stack entries per lane kept in LDS; deeper entries spill to private memory
   int persistent = 0;            // 1: a fixed grid of waves pulls work units from a global cursor (one atomic per unit)
@@ -284,6 +285,13 @@ int CheckStack(const rt_scene *s, rt::KernelArgs &a, uint32_t block)
   return RT_OK;
 }
 
+// The quarter waves of split units may work four lanes per ray: four-wide quantized records, and the tree's worst-case stack
+// within the LDS columns of a quad (nothing of that mode spills to private memory).
+bool CoopFits(const rt_scene *s, const rt::KernelArgs &a)
+{
+  return s->split_coop && s->width == 4 && s->quant && static_cast<uint32_t>(s->flat.stack4) <= 4u * a.stack_entries;
+}
+
 // Work units of a launch over a.n rays: 8x8 pixel tiles when the rays are declared an image, else runs of 64.
 void SetShape(const rt_scene *s, rt::KernelArgs &a, int mode)
 {
@@ -404,6 +412,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
       // four shorter waves instead of one long one, for a few percent more waves in total.
       a.split_units = std::min(static_cast<uint32_t>(s->split_units), a.ntasks);
       grid = (a.ntasks + 3u * a.split_units + wpb - 1u) / wpb;
+      a.coop = CoopFits(s, a) ? 1u : 0u;
     }
     if (a.order) a.prio_slots = static_cast<uint32_t>(static_cast<uint64_t>(a.ntasks) * static_cast<uint32_t>(s->prio_permille) / 1000u);
     // only the launch that ends a period records its costs: the others save the atomics, and an order from one camera
@@ -420,6 +429,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     a.order = s->d_fb_order[newest];
     a.split_units = std::min(static_cast<uint32_t>(s->split_units), a.ntasks);   // ... split like the launches it stands for
     grid = (a.ntasks + 3u * a.split_units + wpb - 1u) / wpb;
+    a.coop = CoopFits(s, a) ? 1u : 0u;
   }
   {
     int rc = CheckStack(s, a, block);
@@ -840,6 +850,9 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "split_units") {
     if (value < 0 || value > 65536) return Fail(RT_ERR_INVALID, "split_units must be in 0..65536");
     s->split_units = value;
+  } else if (k == "split_coop") {
+    if (value < 0 || value > 1) return Fail(RT_ERR_INVALID, "split_coop must be 0 or 1");
+    s->split_coop = value;
   } else if (k == "prio_permille") {
     if (value < 0 || value > 1000) return Fail(RT_ERR_INVALID, "prio_permille must be in 0..1000");
     s->prio_permille = value;

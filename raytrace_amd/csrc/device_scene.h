@@ -49,6 +49,8 @@ struct KernelArgs {
   uint32_t n;
   uint32_t ntasks;            // wave-sized work items: ceil(n/64), or the number of 8x8 tiles
   uint32_t split_units;       // the first this-many units of `order` are traced by four waves each, a quarter of the unit's rays per wave
+  uint32_t coop;              // 1: the quarter waves of split units work four lanes per ray (four-wide quantized records; the tree's
+                              // worst-case stack must fit 4 * stack_entries, the LDS columns of a quad)
   uint32_t refill_min;        // RefillHitKernel: idle lanes of a wave that trigger handing out new rays
   uint32_t prio_slots;        // the first this-many dispatch slots run at raised issue priority (0 = none)
   uint32_t cost_radius;       // a unit's cost is also recorded for its neighbours within this many units (<= 3)

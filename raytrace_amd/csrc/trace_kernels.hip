@@ -69,6 +69,7 @@ struct Best {
   uint32_t id;
 };
 
+
 // The records of a leaf are fetched two at a time, before either is tested, so a leaf of up to two triangles exposes
 // one memory latency and a full leaf two, instead of one per triangle (a leaf's records are consecutive).
 template <bool COUNT>
@@ -105,36 +106,48 @@ __device__ __forceinline__ void LeafTest(const KernelArgs &p, const RayCtx &r, u
 // lds_n + kDeepEntries >= the worst case of the tree (3 * depth + 1 for four-wide nodes).
 // The LDS column is addressed through an LDS-qualified pointer and the private part by plain array indexing, so no
 // access ever goes through a generic (flat) pointer that would have to be told apart at run time.
+// The stack pointer IS the LDS address of the lane's next free entry (its column in row 0 plus 512 bytes per entry held), so a
+// push or a pop costs no address arithmetic and the column's base need not stay in a register through the traversal loop:
+// whether the stack is empty, and whether an entry lives in LDS or in the private part, are comparisons with two wave-uniform
+// addresses (a lane's column offset, 4 * lane, is smaller than one entry's 512 bytes).
 typedef __attribute__((address_space(3))) uint32_t LdsWord;
+constexpr uint32_t kEntryBytes = 512u;   // one entry of all 64 lanes: 64 references + 64 distances
 struct Stack {
-  LdsWord *col;      // this lane's LDS column: entry e = {col[e * 128], col[e * 128 + 64]}
-  uint32_t lds_n;    // entries per lane held in LDS
-  uint32_t sp;
+  uint32_t top;      // LDS byte address of this lane's next free entry
+  uint32_t first;    // wave-uniform: LDS byte address of the wave's part
+  uint32_t limit;    // wave-uniform: first + kEntryBytes * (entries per lane held in LDS)
 };
+
+__device__ __forceinline__ Stack MakeStack(uint2 *wave_lds, uint32_t lane, uint32_t lds_entries)
+{
+  const uint32_t first = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((LdsWord *)reinterpret_cast<uint32_t *>(wave_lds)));
+  return Stack{first + 4u * lane, first, first + kEntryBytes * lds_entries};
+}
+__device__ __forceinline__ uint32_t StackDepth(const Stack &st) { return (st.top - st.first) / kEntryBytes; }
 
 __device__ __forceinline__ void Push(Stack &st, uint2 *deep, uint32_t ref, float t)
 {
-  if (st.sp < st.lds_n) {
-    LdsWord *slot = st.col + st.sp * 128u;
+  if (st.top < st.limit) {
+    LdsWord *slot = reinterpret_cast<LdsWord *>(st.top);
     slot[0] = ref; slot[64] = __float_as_uint(t);
   } else {
-    deep[st.sp - st.lds_n] = make_uint2(ref, __float_as_uint(t));
+    deep[(st.top - st.limit) / kEntryBytes] = make_uint2(ref, __float_as_uint(t));
   }
-  st.sp++;
+  st.top += kEntryBytes;
 }
 
 // Next reference worth visiting: entries whose box starts beyond the best hit found since they were pushed are
 // dropped without fetching their node (equal distances are kept: exact ties resolve by triangle index).
 __device__ __forceinline__ uint32_t Pop(Stack &st, const uint2 *deep, float tbest)
 {
-  while (st.sp) {
-    st.sp--;
+  while (st.top >= st.first + kEntryBytes) {
+    st.top -= kEntryBytes;
     uint32_t ref, tbits;
-    if (st.sp < st.lds_n) {
-      const LdsWord *slot = st.col + st.sp * 128u;
+    if (st.top < st.limit) {
+      const LdsWord *slot = reinterpret_cast<const LdsWord *>(st.top);
       ref = slot[0]; tbits = slot[64];
     } else {
-      const uint2 e = deep[st.sp - st.lds_n];
+      const uint2 e = deep[(st.top - st.limit) / kEntryBytes];
       ref = e.x; tbits = e.y;
     }
     if (__uint_as_float(tbits) <= tbest) return ref;
@@ -176,6 +189,127 @@ __device__ __forceinline__ uint32_t Descend4(Stack &st, uint2 *deep, bool h0, bo
   if (h1 && r1 != next) Push(st, deep, r1, t1);
   if (h0 && r0 != next) Push(st, deep, r0, t0);
   return next;
+}
+
+// ---- cooperative quarter waves: four lanes per ray ---------------------------------------------------------------
+// A launch ends with its longest wave, and the longest waves are those of the few tiles whose rays graze the model: a
+// single ray of them fetches ~90 records one after the other, whatever its 63 neighbours do.  The SPLIT kernels already give
+// such a tile to four waves of 16 rays; those waves leave 48 lanes idle.  Here the idle lanes work: lane 4r + c holds ray r
+// (of 16) and takes CHILD c of the ray's current four-wide node (one 16-byte load and one slab test per lane instead of four)
+// or TRIANGLE c of its leaf (one record and one triangle test instead of up to four); the quad then agrees on the nearest
+// child / the closest hit with quad-permute DPP operations, which cost one vector instruction each.  The four lanes of a
+// quad hold identical copies of the ray, the best hit, the current reference and the stack pointer at every step, so
+// control flow diverges between quads only and the DPP operations never read a disabled lane.
+// The stack of ray r lives in the LDS columns of its four lanes (entry e in row e / 4, column 4r + e % 4): four times the
+// depth of a lane's LDS part, and nothing spills to private memory (the host launches this mode only if the tree fits).
+template <int CTRL>
+__device__ __forceinline__ uint32_t QuadMov(uint32_t x)
+{
+  return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(x), CTRL, 0xF, 0xF, true));
+}
+constexpr int kQuadSwap1 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int kQuadSwap2 = 0x4E;   // quad_perm:[2,3,0,1]
+__device__ __forceinline__ uint32_t QuadMinU32(uint32_t x)
+{
+  x = min(x, QuadMov<kQuadSwap1>(x));
+  return min(x, QuadMov<kQuadSwap2>(x));
+}
+__device__ __forceinline__ uint32_t QuadOr(uint32_t x)
+{
+  x |= QuadMov<kQuadSwap1>(x);
+  return x | QuadMov<kQuadSwap2>(x);
+}
+
+constexpr uint32_t kInfBits = 0x7F800000u;
+
+// Entry e of this lane's ray: row e / 4 of the [entry][reference | distance][lane] layout, column (quad base) + e % 4.
+__device__ __forceinline__ LdsWord *CoopSlot(LdsWord *quad_col, uint32_t e) { return quad_col + (e >> 2) * 128u + (e & 3u); }
+
+__device__ __forceinline__ uint32_t CoopPop(LdsWord *quad_col, uint32_t &sp, float tbest)
+{
+  while (sp) {
+    sp--;
+    const LdsWord *slot = CoopSlot(quad_col, sp);
+    const uint32_t ref = slot[0], tbits = slot[64];
+    if (__uint_as_float(tbits) <= tbest) return ref;
+  }
+  return kDone;
+}
+
+// Traverses the rays of a quarter unit, four lanes per ray.  `cidx` = lane & 3; every lane of a quad enters with the same ray.
+// Returns the wave's iteration count (all lanes the same value).
+template <bool COUNT>
+__device__ __forceinline__ uint32_t CoopTraverse(const KernelArgs &p, const RayCtx &r, const RayCtxQ &rq, LdsWord *quad_col, uint32_t cidx,
+                                                 bool live, Best &best, uint32_t &nnode, uint32_t &ntri, uint32_t &nleaf, uint32_t &maxsp)
+{
+  uint32_t cur = live ? 0u : kDone, sp = 0u, iters = 0u;
+  for (;;) {
+    iters++;
+    const bool inner = !(cur & kLeafBitDev);
+    const bool parked = !inner && cur != kDone;
+    const unsigned long long mi = __ballot(inner), ml = __ballot(parked);
+    if ((mi | ml) == 0ull) break;
+    const uint32_t ni = __popcll(mi), nl = __popcll(ml);
+    if (ni != 0u && nl * 100u < p.leaf_pct * (ni + nl)) {
+      if (inner) {
+        if (COUNT && cidx == 0u) nnode++;
+        const uint4 c = reinterpret_cast<const uint4 *>(p.nodes)[static_cast<size_t>(cur) * 4u + cidx];
+        float t;
+        const bool h = SlabTestQ(rq, c.x, c.y, c.z, best.t, t);
+        // nearest hit child of the quad: entry distances are >= 0, so their bit patterns order like the floats; the two lowest
+        // mantissa bits are replaced by the slot number, which makes the keys of a quad distinct (lowest slot wins a tie, as in
+        // Descend4; a 3-ulp change of the ordering key changes no result, and the distance pushed below is the exact one)
+        const uint32_t key = h ? ((__float_as_uint(t) & ~3u) | cidx) : 0xFFFFFFFFu;
+        const uint32_t kmin = QuadMinU32(key);
+        const bool take = key == kmin && h;
+        const uint32_t next = QuadOr(take ? c.w : 0u);
+        // the other hit children go on the ray's stack, each lane writing its own entry at its rank among the quad's pushes
+        const bool push = h && !take;
+        const unsigned long long pm = __ballot(push);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u));
+        const uint32_t base = QuadMov<0x00>(below);                               // pushes in lanes below the quad
+        const uint32_t total = QuadMov<0xFF>(below + (push ? 1u : 0u)) - base;    // pushes of the quad
+        if (push) {
+          LdsWord *slot = CoopSlot(quad_col, sp + (below - base));
+          slot[0] = c.w; slot[64] = __float_as_uint(t);
+        }
+        sp += total;
+        if (COUNT) maxsp = max(maxsp, sp);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // a pop below may read what another lane of the quad just wrote
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        cur = kmin != 0xFFFFFFFFu ? next : CoopPop(quad_col, sp, best.t);
+      }
+    } else if (parked) {
+      if (COUNT && cidx == 0u) nleaf += (cur & 7u) ? 1u : 0u;
+      const uint32_t first = (cur & 0x7FFFFFFFu) >> 3, cnt = cur & 7u;
+      for (uint32_t j = 0; j < cnt; j += 4u) {   // leaves hold at most four triangles: one round
+        const bool has = j + cidx < cnt;
+        float t = 0.f, u = 0.f, v = 0.f;
+        uint32_t id = RT_MISS_ID;
+        bool better = false;
+        if (has) {
+          const float4 *tp = p.tris + static_cast<size_t>(first + j + cidx) * 3u;
+          const float4 a = LoadF4(tp), e1 = LoadF4(tp + 1), e2 = LoadF4(tp + 2);
+          const bool ok = TriTest(a.x, a.y, a.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z, r, t, u, v);
+          id = __float_as_uint(a.w);
+          better = ok && (t < best.t || (t == best.t && id < best.id));
+          if (COUNT) ntri++;
+        }
+        // accepted hits have t > 1e-6: positive floats, ordered like their bit patterns
+        const uint32_t tmin = QuadMinU32(better ? __float_as_uint(t) : kInfBits);
+        const bool cand = better && __float_as_uint(t) == tmin;
+        const uint32_t idmin = QuadMinU32(cand ? id : RT_MISS_ID);     // equal distances: the lower triangle index
+        const bool win = cand && id == idmin;
+        const uint32_t wu = QuadOr(win ? __float_as_uint(u) : 0u), wv = QuadOr(win ? __float_as_uint(v) : 0u);
+        if (tmin != kInfBits) {
+          best.t = __uint_as_float(tmin); best.id = idmin; best.u = __uint_as_float(wu); best.v = __uint_as_float(wv);
+        }
+      }
+      cur = CoopPop(quad_col, sp, best.t);
+    }
+  }
+  return iters;
 }
 
 #ifndef RT_SCALAR_NODE
@@ -322,8 +456,8 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
   // the wave's index is the same in all of its lanes: saying so keeps what depends on it (the dispatch slot, the order lookup,
   // the unit's position) in scalar registers and scalar loads, off the vector memory path the rays are about to need
   // (the LDS stack's base stays a per-lane vector value, as every access to it wants it)
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint2 *const wave_lds = lds_stack + wave * p.stack_entries * 64u;   // stack_entries >= 8: 4 KB for the record exchange
+  const uint32_t lane = threadIdx.x & 63u, wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint2 *const wave_lds = lds_stack + wave_s * p.stack_entries * 64u;   // stack_entries >= 8: 4 KB for the record exchange
   uint2 deep[kDeepEntries];   // private memory; touched only by rays whose stack outgrows the LDS part
 
   // A wave handles one work unit per round.  Static launch: one round, the unit's position in the dispatch order
@@ -371,8 +505,11 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
       pos.x0 = (unit - ty * tiles_x) * 8u + (quarter ? (slot & 1u) * 4u : 0u);
       pos.y0 = ty * 8u + (quarter ? (slot & 2u) * 2u : 0u);
     }
+    // cooperative quarter wave (four-wide quantized records only): lane 4r + c works for ray r of the quarter's 16
+    const bool coop = SPLIT && QUANT && WIDTH == 4 && quarter && p.coop != 0u;
+    const uint32_t rlane = coop ? lane >> 2 : lane;
     uint32_t idx;
-    const bool valid = RayOfLane<SPLIT>(p, pos, lane, idx);
+    const bool valid = RayOfLane<SPLIT>(p, pos, rlane, idx);
     float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0, rec3 = rec0;   // this lane's output record
     uint32_t wave_cost = 0;
     uint32_t c_node = 0, c_tri = 0, c_leaf = 0, c_hit = 0, c_deep = 0;  // instrumented build: this lane's counts
@@ -385,7 +522,7 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
         // operations in the same order as the host generator, so the rays are bit-identical to its table
         const float ex = p.img_w / 2.f, ey = p.img_h / 2.f, ez = static_cast<float>(-5 * static_cast<int>(p.img_w));
         uint32_t px, py;
-        PixelOfLane<SPLIT>(pos, lane, px, py);
+        PixelOfLane<SPLIT>(pos, rlane, px, py);
         const float tx = static_cast<float>(px) - ex, ty = static_cast<float>(py) - ey, tz = 0.f - ez;
         const float len = sqrtf(tx * tx + ty * ty + tz * tz);
         in_o = make_float4(p.cam[0], p.cam[1], p.cam[2], 1.f);
@@ -421,7 +558,7 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
       RayCtxQ rq;
       if (QUANT) SetupRayQ(rq, r, p.grid, p.scale);
       Best best{kFltMax, 0.f, 0.f, RT_MISS_ID};
-      Stack st{(LdsWord *)(reinterpret_cast<uint32_t *>(wave_lds) + lane), p.stack_entries, 0u};
+      Stack st = MakeStack(wave_lds, lane, p.stack_entries);
       uint32_t cur = live ? 0u : kDone;
       uint32_t nnode = 0, ntri = 0, nleaf = 0, maxsp = 0;
 
@@ -431,6 +568,10 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
       // on a few lanes.  Switching to the leaf step once `leaf_pct` percent of the busy lanes are parked sits
       // between the two and shortens both the average and the longest wave.
       uint32_t iters = 0;
+      if (SPLIT && QUANT && WIDTH == 4 && coop) {
+        LdsWord *quad_col = (LdsWord *)(reinterpret_cast<uint32_t *>(wave_lds) + (lane & ~3u));
+        iters = CoopTraverse<COUNT>(p, r, rq, quad_col, lane & 3u, live, best, nnode, ntri, nleaf, maxsp);
+      } else
       for (;;) {
         iters++;
         const bool inner = !(cur & kLeafBitDev);
@@ -451,7 +592,7 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
               }
             }
             if (!stepped) cur = NodeStep<WIDTH, QUANT>(p, r, rq, cur, best.t, st, deep);
-            if (COUNT) maxsp = max(maxsp, st.sp);
+            if (COUNT) maxsp = max(maxsp, StackDepth(st));
           }
         } else if (parked) {
           if (COUNT) nleaf += (cur & 7u) ? 1u : 0u;
@@ -462,19 +603,29 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
 
       wave_cost = iters;
       if (COUNT) {
-        c_node += nnode; c_tri += ntri; c_leaf += nleaf; c_hit += best.id != RT_MISS_ID ? 1u : 0u;
+        c_node += nnode; c_tri += ntri; c_leaf += nleaf;
+        c_hit += best.id != RT_MISS_ID && (!coop || (lane & 3u) == 0u) ? 1u : 0u;   // a cooperative quad holds one ray
         c_deep = maxsp;
       }
 
       // ---- output record (tracekernel.ck:282-286 miss defaults, :373-399 hit) ----------
       const bool hit = best.id != RT_MISS_ID;
-      if (p.hits16) {
+      // of a cooperative quad, lane 0 writes the ray's outputs (whether the wave is one is worked out again rather than kept
+      // in a register across the traversal loop)
+      bool writer = true;
+      if (SPLIT && QUANT && WIDTH == 4) {
+        uint32_t w = threadIdx.x >> 6;
+        asm volatile("" : "+v"(w));
+        const bool q = blockIdx.x * p.waves_per_block + __builtin_amdgcn_readfirstlane(w) < 4u * p.split_units;
+        writer = !(q && p.coop != 0u) || (threadIdx.x & 3u) == 0u;
+      }
+      if (p.hits16 && writer) {
         rt_hit16 h;
         h.triangle_id = best.id; h.t = best.t; h.u = hit ? best.u : 0.f; h.v = hit ? best.v : 0.f;
         StoreStreamF4<MODE != kModeTrace>(reinterpret_cast<float4 *>(p.hits16 + idx), make_float4(__uint_as_float(h.triangle_id), h.t, h.u, h.v));
       }
       float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.hits || (MODE == kModeTrace && p.rgba)) {
+      if ((p.hits || (MODE == kModeTrace && p.rgba)) && writer) {
         float4 out_o = in_o, out_n = in_d, out_d = in_d;
         float out_u = 0.f, out_v = 0.f;
         if (MODE == kModeTrace && !live) {
@@ -533,6 +684,7 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
       quarter_out = blockIdx.x * p.waves_per_block + __builtin_amdgcn_readfirstlane(w) < 4u * p.split_units;   // never with a cursor
       pos.sub = quarter_out ? 1u : 0u;
     }
+    const bool coop_out = SPLIT && QUANT && WIDTH == 4 && quarter_out && p.coop != 0u;
     if (p.hits) {
       // 64-byte records, one per lane: written straight from the lanes, every store instruction would scatter 64
       // 16-byte pieces over 32 cache lines.  The wave's traversal stack is idle by now, so the records are
@@ -540,9 +692,12 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
       // 512-byte rows of an 8x8 tile in image mode).
       // [record][quarter ^ swizzle(record)]: the swizzle spreads the 64-byte-strided writes over all banks
       float4 *tile = reinterpret_cast<float4 *>(wave_lds);
-      const uint32_t wsw = (lane >> 2) & 3u;
-      tile[lane * 4u + (0u ^ wsw)] = rec0; tile[lane * 4u + (1u ^ wsw)] = rec1;
-      tile[lane * 4u + (2u ^ wsw)] = rec2; tile[lane * 4u + (3u ^ wsw)] = rec3;
+      const uint32_t wl = coop_out ? lane >> 2 : lane;   // which record of the unit this lane holds
+      const uint32_t wsw = (wl >> 2) & 3u;
+      if (!coop_out || (lane & 3u) == 0u) {
+        tile[wl * 4u + (0u ^ wsw)] = rec0; tile[wl * 4u + (1u ^ wsw)] = rec1;
+        tile[wl * 4u + (2u ^ wsw)] = rec2; tile[wl * 4u + (3u ^ wsw)] = rec3;
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -681,7 +836,7 @@ __global__ void __launch_bounds__(256, kRefillWavesPerSimd) RefillHitKernel(Kern
   SetupRay(r, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, p.scale);   // defined values for lanes that never get a ray
   SetupRayQ(rq, r, p.grid, p.scale);
   Best best{kFltMax, 0.f, 0.f, RT_MISS_ID};
-  Stack st{(LdsWord *)(reinterpret_cast<uint32_t *>(wave_lds) + lane), p.stack_entries, 0u};
+  Stack st = MakeStack(wave_lds, lane, p.stack_entries);
   constexpr uint32_t kNoRay = 0xFFFFFFFFu;
   uint32_t cur = kDone, idx = kNoRay;
   float ray_ow = 0.f, ray_dw = 0.f;   // fourth components of the ray record: a missed ray's record passes them through
@@ -733,7 +888,7 @@ __global__ void __launch_bounds__(256, kRefillWavesPerSimd) RefillHitKernel(Kern
         SetupRayQ(rq, r, p.grid, p.scale);
         ray_ow = o.w; ray_dw = d.w;
         best = Best{kFltMax, 0.f, 0.f, RT_MISS_ID};
-        st.sp = 0u;
+        st.top = st.first + 4u * lane;
         cur = 0u;
       }
       c_next += take;

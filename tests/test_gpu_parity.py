@@ -636,12 +636,16 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
         dict(image_width=W, feedback=1, split_units=65536, block_threads=256, width=4),   # capped: every unit is split
         dict(image_width=0, feedback=1, split_units=501, block_threads=128),
         dict(image_width=W, feedback=1, split_units=100, quantized=0, feedback_radius=0),
+        dict(image_width=W, feedback=1, split_units=7, width=4, split_coop=0),       # quarter waves with one ray per lane
+        dict(image_width=W, feedback=1, split_units=3600, width=4, split_coop=1),    # every unit as four cooperative quarter waves
+        dict(image_width=0, feedback=1, split_units=300, width=4, split_coop=1, block_threads=256),
+        dict(image_width=W, feedback=1, split_units=64, width=4, split_coop=1, lds_stack=8, leaf_pct=20),
         dict(image_width=W, feedback=1, feedback_period=1, width=4),
         dict(image_width=W, feedback=1, feedback_period=2, block_threads=128),
         dict(image_width=0, feedback=1, feedback_period=3, width=4),
     ]
-    defaults = dict(width=2, quantized=1, block_threads=64, image_width=0, leaf_pct=50, persistent=0, split_units=32, feedback_period=4,
-                    persistent_waves=24, lds_stack=10, centre_first=1, feedback=0, feedback_radius=1, feedback_share=96)
+    defaults = dict(width=2, quantized=1, block_threads=64, image_width=0, leaf_pct=50, persistent=0, split_units=32, split_coop=1,
+                    feedback_period=4, persistent_waves=24, lds_stack=10, centre_first=1, feedback=0, feedback_radius=1, feedback_share=96)
     for cfg in settings:
         for k, v in {**defaults, **cfg}.items():
             scene.set_param(k, v)
@@ -658,6 +662,57 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
             out = launch(shifted)
             assert np.array_equal(bits(out), bits(np.roll(base[:n], rep * 17, axis=0))), (n, rep)
     scene.close()
+
+
+def test_cooperative_quarter_waves_are_exact(rt, oracle, gpu):
+    """The costliest work units of a cost-sorted launch are traced by four waves of 16 rays each, FOUR LANES PER RAY (one
+    child box or one leaf triangle per lane, quad-permute reductions).  Every record -- 64-byte and 16-byte, table rays and
+    rays generated in the kernel, image tiles whose edges cut the 4x4 blocks, linear ray sets with a ragged end -- must equal
+    the one-ray-per-lane launch bit for bit, and the oracle on a sample.  A tree too deep for the quads' LDS columns falls
+    back to the one-ray-per-lane quarters (same bits again)."""
+    import torch
+    stream = torch.cuda.current_stream().cuda_stream
+    for model, W, H in (("dragon.obj", 611, 347), ("teapot.obj", 256, 130)):
+        mesh = rt.Mesh.load_obj(os.path.join(MODELS, model), "tolerant")
+        bvh = rt.BVH(mesh, "fixed")
+        origin = rt.frame_camera(bvh.root_box, W, H)
+        rays = rt.primary_rays(W, H, origin)
+        n = len(rays)
+        d_rays = torch.from_numpy(rays).cuda()
+        scene = rt.Scene(mesh, bvh, device=gpu, width=4)
+        for k, v in dict(width=4, feedback=1, feedback_period=2, split_units=0).items():
+            scene.set_param(k, v)
+        want = scene.intersect(rays)
+        compare(rt, oracle, mesh, rays, want, np.arange(0, n, 97))
+        for hint, units, n_used in ((W, 1 << 16, n), (W, 40, n), (0, 1 << 16, n - 13), (0, 9, n)):
+            scene.set_param("image_width", hint)
+            scene.set_param("split_units", units)
+            for coop, stack in ((1, 10), (0, 10), (1, 8)):
+                scene.set_param("split_coop", coop)
+                scene.set_param("lds_stack", stack)
+                for rep in range(5):     # launches 0 and 1 build the order; from launch 2 on the head of it is split
+                    full = torch.full((n, 16), -3.0, dtype=torch.float32, device="cuda")
+                    small = torch.full((n, 4), -3.0, dtype=torch.float32, device="cuda")
+                    scene.intersect_async(d_rays.data_ptr(), n_used, full.data_ptr(), small.data_ptr(), stream)
+                    torch.cuda.synchronize()
+                    got, got16 = full.cpu().numpy(), small.cpu().numpy()
+                    assert np.array_equal(bits(got[:n_used]), bits(want[:n_used])), (model, hint, units, coop, stack, rep)
+                    assert np.all(got[n_used:] == -3.0) and np.all(got16[n_used:] == -3.0)
+                    assert np.array_equal(bits(got16[:n_used, 0]), bits(want[:n_used, 14])) and np.array_equal(bits(got16[:n_used, 1]), bits(want[:n_used, 15]))
+                    assert np.array_equal(bits(got16[:n_used, 2:4]), bits(want[:n_used, 12:14]))
+        # rays generated in the kernel, cooperative quarters included
+        scene.set_param("image_width", W)
+        scene.set_param("split_units", 1 << 16)
+        scene.set_param("split_coop", 1)
+        for rep in range(4):
+            full = torch.full((n, 16), -3.0, dtype=torch.float32, device="cuda")
+            scene.trace_primary(W, H, origin, full.data_ptr(), None, stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(bits(full.cpu().numpy()), bits(want)), (model, rep)
+        # the instrumented launch follows the same split and counts the same records as the host mirror of the traversal
+        dev = scene.count_fetches_device(d_rays.data_ptr(), n)
+        assert dev["rays"] == n and dev["rays_hit"] == int((want[:, 14].view(np.uint32) != rt.MISS_ID).sum())
+        scene.close()
 
 
 @pytest.mark.parametrize("W,H", [(640, 360), (203, 97), (8, 8), (1, 1)])

@@ -71,6 +71,10 @@ def test_static_entry_point_allocates_nothing_and_tells_scenes_apart():
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     got = [torch.full((W * H, 16), -7.0, dtype=torch.float32, device="cuda") for _ in range(2)]
+    # first use of a stream: the HIP runtime sets up the queue behind it, including its arena for the kernels' private memory
+    # (the traversal stack's spill part); that happens once per stream, on the first launch there, whoever launches
+    for k in (0, 1):
+        scenes[k].intersect_static(rays_d[k].data_ptr(), W * H, got[k].data_ptr(), None, streams[k].cuda_stream)
     torch.cuda.synchronize()
     free_before = torch.cuda.mem_get_info()[0]
     try:
@@ -85,10 +89,12 @@ def test_static_entry_point_allocates_nothing_and_tells_scenes_apart():
         for rep in range(4):
             for k in (0, 1):
                 got[k].fill_(-7.0)
+                torch.cuda.synchronize()
+                free_now = torch.cuda.mem_get_info()[0]     # (the comparisons below allocate through torch: measured per call)
                 scenes[k].intersect_static(rays_d[k].data_ptr(), W * H, got[k].data_ptr(), None, streams[rep & 1].cuda_stream)
                 torch.cuda.synchronize()
+                assert torch.cuda.mem_get_info()[0] == free_now, (rep, k)
                 assert torch.equal(got[k].view(torch.int32), want[k].view(torch.int32)), (rep, k)
-        assert torch.cuda.mem_get_info()[0] == free_before
     finally:
         for sc in scenes:
             sc.close()

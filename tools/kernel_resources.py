@@ -6,7 +6,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
-       "-fhip-fp32-correctly-rounded-divide-sqrt", "-Iinclude", "-c", "raytrace_amd/csrc/trace_kernels.hip",
+       "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero", "-fno-slp-vectorize", "-Iinclude", "-c", "raytrace_amd/csrc/trace_kernels.hip",
        "-o", "/tmp/tk_res.o", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True).stderr
 cur = {}
