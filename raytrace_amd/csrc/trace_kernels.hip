@@ -782,9 +782,9 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
 // are.  Linear ray sets only (no image tiles).  Every wave leaves once the cursor has passed the last ray and
 // its lanes have finished -- an exit every wave reaches, whatever the rays are.
 
-// The 64-byte hit record of ray `idx` (tracekernel.ck:282-286 miss defaults, :373-399 hit), as the batch kernel's output
-// stage builds it, written straight from the lane: retiring lanes hold unrelated rays, there is no tile to exchange.
-__device__ __forceinline__ void StoreFullRecord(const KernelArgs &p, uint32_t idx, const Best &best, const float4 in_o, const float4 in_d)
+// The 64-byte hit record of a ray (tracekernel.ck:282-286 miss defaults, :373-399 hit) as four 16-byte quarters.
+__device__ __forceinline__ void HitRecord(const KernelArgs &p, const Best &best, const float4 in_o, const float4 in_d, float4 &rec0, float4 &rec1,
+                                          float4 &rec2, float4 &rec3)
 {
   float4 out_o = in_o, out_n = in_d, out_d = in_d;
   float out_u = 0.f, out_v = 0.f;
@@ -797,12 +797,14 @@ __device__ __forceinline__ void StoreFullRecord(const KernelArgs &p, uint32_t id
     out_o = make_float4(w * v0.x + u * v1.x + v * v2.x, w * v0.y + u * v1.y + v * v2.y, w * v0.z + u * v1.z + v * v2.z, 1.f);
     float nx, ny, nz;
     if (f.s[4] < p.nnormals && f.s[5] < p.nnormals && f.s[6] < p.nnormals) {
+      // u*N[n0] + v*N[n1] + (1-u-v)*N[n2]: the reference's pairing (tracekernel.ck:376)
       const float4 *np4 = reinterpret_cast<const float4 *>(p.normals);
       const float4 n0 = np4[f.s[4]], n1 = np4[f.s[5]], n2 = np4[f.s[6]];
       nx = u * n0.x + v * n1.x + w * n2.x;
       ny = u * n0.y + v * n1.y + w * n2.y;
       nz = u * n0.z + v * n1.z + w * n2.z;
     } else {
+      // no vertex normals in the scene: unit geometric normal (one hardware reciprocal square root)
       const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
       const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
       nx = e1y * e2z - e1z * e2y; ny = e1z * e2x - e1x * e2z; nz = e1x * e2y - e1y * e2x;
@@ -816,20 +818,56 @@ __device__ __forceinline__ void StoreFullRecord(const KernelArgs &p, uint32_t id
     out_d = make_float4(in_d.x, in_d.y, in_d.z, 0.f);
     out_u = u; out_v = v;
   }
-  // (the four quarters of a record leave the lane in four instructions: 1.8x the record bytes reach HBM as partial writes,
-  // streamed or not, and the launch time does not depend on which)
-  float4 *out = reinterpret_cast<float4 *>(p.hits + idx);
-  StoreStreamF4<true>(out, out_o);
-  StoreStreamF4<true>(out + 1, out_d);
-  StoreStreamF4<true>(out + 2, out_n);
-  StoreStreamF4<true>(out + 3, make_float4(out_u, out_v, __uint_as_float(best.id), best.t));
+  rec0 = out_o; rec1 = out_d; rec2 = out_n;
+  rec3 = make_float4(out_u, out_v, __uint_as_float(best.id), best.t);
+}
+
+// Finished rays leave a refilling wave at unrelated times and hold unrelated records, so there is no tile to exchange as in the
+// batch kernel; written straight from the lanes, the four 16-byte quarters of a record leave in four store instructions and
+// reach memory as partial lines (1.8x the record bytes on the HBM side).  Instead the retiring lanes park their records in
+// their own stack columns (a finished ray's stack is empty: rows 0..7 of its column take the 16 dwords), a small table maps
+// the rank of a retiring lane to its lane number and ray index, and the wave then writes sixteen WHOLE records per store
+// instruction: lane 4s + q fetches quarter q of the s-th retiring record.
+constexpr uint32_t kRetireTableBytes = 512;   // per wave, behind its stack part: 64 lane numbers + 64 ray indices
+
+__device__ __forceinline__ void RetireRecords(const KernelArgs &p, uint32_t stack_first, uint32_t lane, bool retiring, uint32_t idx,
+                                              const float4 &rec0, const float4 &rec1, const float4 &rec2, const float4 &rec3)
+{
+  const unsigned long long rm = __ballot(retiring);
+  const uint32_t nret = __popcll(rm);
+  if (nret == 0u) return;
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(rm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(rm), 0u));
+  LdsWord *const col = reinterpret_cast<LdsWord *>(stack_first + 4u * lane);              // row k: col[128 k] and col[128 k + 64]
+  LdsWord *const table = reinterpret_cast<LdsWord *>(stack_first + kEntryBytes * p.stack_entries);
+  if (retiring) {
+    const float4 rec[4] = {rec0, rec1, rec2, rec3};
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q) {
+      col[(2u * q) * 128u] = __float_as_uint(rec[q].x); col[(2u * q) * 128u + 64u] = __float_as_uint(rec[q].y);
+      col[(2u * q + 1u) * 128u] = __float_as_uint(rec[q].z); col[(2u * q + 1u) * 128u + 64u] = __float_as_uint(rec[q].w);
+    }
+    table[rank] = lane; table[64u + rank] = idx;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint32_t q = lane & 3u;
+  for (uint32_t s = lane >> 2; s < nret; s += 16u) {   // sixteen records per round
+    const uint32_t from = table[s], ray = table[64u + s];
+    const LdsWord *src = reinterpret_cast<const LdsWord *>(stack_first + 4u * from) + (2u * q) * 128u;
+    const float4 v = make_float4(__uint_as_float(src[0]), __uint_as_float(src[64]), __uint_as_float(src[128]), __uint_as_float(src[192]));
+    StoreStreamF4<true>(reinterpret_cast<float4 *>(p.hits + ray) + q, v);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the columns go back to being stacks
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __global__ void __launch_bounds__(256, kRefillWavesPerSimd) RefillHitKernel(KernelArgs p)
 {
   extern __shared__ uint2 lds_stack[];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint2 *const wave_lds = lds_stack + wave * p.stack_entries * 64u;
+  const uint32_t lane = threadIdx.x & 63u, wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint2 *const wave_lds = lds_stack + wave_s * (p.stack_entries * 64u + kRetireTableBytes / 8u);   // stack part, then the retire table
   uint2 deep[kDeepEntries];
   RayCtx r;
   RayCtxQ rq;
@@ -873,15 +911,17 @@ __global__ void __launch_bounds__(256, kRefillWavesPerSimd) RefillHitKernel(Kern
         o = LoadStreamF4<true>(rp);
         d = LoadStreamF4<true>(rp + 1);
       }
-      if (cur == kDone && idx != kNoRay) {
+      const bool retiring = cur == kDone && idx != kNoRay;
+      float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0, rec3 = rec0;
+      if (retiring) {
         const bool hit = best.id != RT_MISS_ID;
         if (p.hits16)
           StoreStreamF4<true>(reinterpret_cast<float4 *>(p.hits16 + idx),
                               make_float4(__uint_as_float(best.id), best.t, hit ? best.u : 0.f, hit ? best.v : 0.f));
-        if (p.hits)
-          StoreFullRecord(p, idx, best, make_float4(r.ox, r.oy, r.oz, ray_ow), make_float4(r.dx, r.dy, r.dz, ray_dw));
-        idx = kNoRay;
+        if (p.hits) HitRecord(p, best, make_float4(r.ox, r.oy, r.oz, ray_ow), make_float4(r.dx, r.dy, r.dz, ray_dw), rec0, rec1, rec2, rec3);
       }
+      if (p.hits) RetireRecords(p, st.first, lane, retiring, idx, rec0, rec1, rec2, rec3);
+      if (retiring) idx = kNoRay;
       if (getting) {
         idx = new_idx;
         SetupRay(r, o.x, o.y, o.z, d.x, d.y, d.z, p.scale);
@@ -1137,7 +1177,7 @@ hipError_t LaunchClosestHit(const KernelArgs &args, int width, bool quant, int m
 hipError_t LaunchRefill(const KernelArgs &a, uint32_t grid, uint32_t block, hipStream_t stream)
 {
   (void)hipGetLastError();
-  const size_t lds = static_cast<size_t>(a.stack_entries) * 8u * block;
+  const size_t lds = (static_cast<size_t>(a.stack_entries) * 512u + kRetireTableBytes) * (block / 64u);   // per wave: stack part + retire table
   if (lds > 64u * 1024u) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&RefillHitKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
