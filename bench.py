@@ -15,8 +15,9 @@ Workloads:
   bunny1080    bunny.obj 1920x1080 primary rays
   dragon4k     dragon.obj 3840x2160 primary rays on one GPU
   ao           bunny_big.obj incoherent AO-style rays (--rays per GPU, default 64 Mi)
-  mirror5      cube_mirror_test.obj 1920x1080: one step = the primary pass + four reflection passes of the
-               full `trace` kernel (rt_trace_pass, records ping-ponged on the device); rays counted = 5 x W x H
+  mirror5      cube_mirror_test.obj and teapot.obj 1920x1080: one step = for each scene the primary pass + four
+               reflection passes of the full `trace` kernel (rt_trace_pass, records ping-ponged on the device);
+               rays counted = those actually traced (a record whose previous pass missed is passed through)
   frames       with N > 1: every rank traces its own dragon1080 frame (weak scaling, no exchange)
 
 The scene is built the way the reference builds it: tolerant OBJ load, core/CentroidBVH build with the
@@ -140,6 +141,161 @@ def timed(dist, steps, fn, finish=None):
     return time.perf_counter() - t0, ev0.elapsed_time(ev1) / max(1, steps)
 
 
+def mirror_pose(rt, bvh):
+    """Camera matrix that looks at cube_mirror_test.obj from the +z side, where the cube sits above the mirror slab and the
+    reflected rays of pass 1 land on it (from -z, the framing of the other workloads, every reflected ray leaves the scene)."""
+    f32 = np.float32
+    c, s = f32(np.cos(2.6)), f32(np.sin(2.6))
+    box = bvh.root_box
+    centre = 0.5 * (box[0, :3] + box[1, :3])
+    dist = f32(8.0) * f32(np.abs(box[1, :3] - box[0, :3]).max())
+    cam = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], f32)
+    cam[:3, 3] = centre - dist * np.array([s, 0, c], f32)
+    return cam
+
+
+def run_mirror5(a, local):
+    """--workload mirror5: BASELINE config 5.  One step = for cube_mirror_test.obj AND teapot.obj a 1920x1080 primary pass plus
+    four reflection passes of the full `trace` kernel (rt_trace_pass; records ping-ponged on the device, as
+    render_client/img_main.cpp:447-498 does for its one bounce).  `value` counts the rays actually traced: a record whose
+    previous pass missed is passed through, not traced (the record passes are reported beside it).  Every pass of both scenes is
+    spot-checked against the CPU oracle (ray regeneration + brute-force closest hit) on a sub-grid, which is also the timed
+    CPU baseline."""
+    W, H = 1920, 1080
+    n = W * H
+    stream = torch.cuda.current_stream().cuda_stream
+    jobs = []
+    for model in ("cube_mirror_test.obj", "teapot.obj"):
+        mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "reference")
+        bvh = rt.BVH(mesh, a.bvh)
+        scene = rt.Scene(mesh, bvh, device=local, width=4)
+        scene.set_param("width", 4)
+        scene.set_param("image_width", W if a.image_hint else 0)
+        scene.set_param("feedback", a.feedback)
+        for kv in a.param:
+            k, v = kv.split("=")
+            scene.set_param(k, int(v))
+        if model.startswith("cube_mirror"):
+            cam, rays_h = mirror_pose(rt, bvh), rt.primary_rays(W, H, (0, 0, 0))
+        else:
+            cam, rays_h = np.eye(4, dtype=np.float32), rt.primary_rays(W, H, rt.frame_camera(bvh.root_box, W, H))
+        jobs.append(types.SimpleNamespace(model=model, mesh=mesh, bvh=bvh, scene=scene, cam=cam, rays_h=rays_h,
+                                          rays_d=torch.from_numpy(rays_h).cuda(), info=scene.info(),
+                                          ping=torch.empty((n, 16), dtype=torch.float32, device="cuda"),
+                                          pong=torch.empty((n, 16), dtype=torch.float32, device="cuda"),
+                                          rgba=torch.empty((n, 4), dtype=torch.float32, device="cuda")))
+
+    def chain(j, after_pass=None):
+        j.scene.trace_pass(j.rays_d.data_ptr(), j.ping.data_ptr(), j.rgba.data_ptr(), n, j.cam, 0, stream)
+        src, dst = j.ping, j.pong
+        if after_pass:
+            after_pass(0, j.rays_d, src)
+        for k in range(1, 5):
+            j.scene.trace_pass(src.data_ptr(), dst.data_ptr(), j.rgba.data_ptr(), n, j.cam, 1, stream)
+            if after_pass:
+                after_pass(k, src, dst)
+            src, dst = dst, src
+
+    def step():
+        for j in jobs:
+            chain(j)
+
+    for _ in range(a.warmup):
+        step()
+    wall, dev_ms = timed(None, a.steps, step)
+    ms_per_step = wall * 1e3 / max(1, a.steps)
+
+    # ---- one checked step: rays traced per pass, records fetched per pass, and the oracle on a sub-grid ----
+    import oracle
+    sgrid = max(1, a.cpu_stride)
+    sel = (np.arange(0, H, sgrid)[:, None] * W + np.arange(0, W, sgrid)[None, :]).reshape(-1)
+    sel_d = torch.from_numpy(sel).cuda()
+    threads = oracle.default_threads()
+    per_scene, traced_total, cpu_secs, cpu_rays, id_bad, t_bad = [], 0, 0.0, 0, 0, 0
+    nodes_total = tris_total = 0
+    for j in jobs:
+        j.scene.set_param("feedback", 0)     # the counting launches below follow no order
+        passes = []
+
+        def check(k, src, dst, j=j, passes=passes):
+            nonlocal traced_total, cpu_secs, cpu_rays, id_bad, t_bad, nodes_total, tris_total
+            torch.cuda.synchronize()
+            live = torch.ones(n, dtype=torch.bool, device="cuda") if k == 0 else (src[:, 14].view(torch.int32) != -1)
+            traced = int(live.sum())
+            hits = int((dst[:, 14].view(torch.int32) != -1).sum())
+            # records fetched: the rays of this pass rebuilt from its input records (tracekernel.ck:227-265) and counted like any others
+            if k == 0:
+                o4 = torch.cat([src[:, 0:3], torch.ones((n, 1), device="cuda")], dim=1)
+                d4 = torch.cat([src[:, 4:7], torch.zeros((n, 1), device="cuda")], dim=1)
+                m = torch.from_numpy(j.cam).cuda()
+                tab = torch.zeros((n, 16), dtype=torch.float32, device="cuda")
+                tab[:, 0:3] = (o4 @ m.T)[:, 0:3]
+                tab[:, 4:7] = (d4 @ m.T)[:, 0:3]
+            else:
+                d4, n4 = src[:, 4:8], src[:, 8:12]
+                s2 = 2.0 * (d4 * n4).sum(dim=1)
+                tab = torch.zeros((n, 16), dtype=torch.float32, device="cuda")
+                tab[:, 0:3] = src[:, 0:3] + n4[:, 0:3] * 0.00001
+                tab[:, 4:7] = d4[:, 0:3] - s2[:, None] * n4[:, 0:3]
+                tab = tab[live].contiguous()
+            tab[:, 3] = 1.0
+            c = j.scene.count_fetches_device(tab.data_ptr(), len(tab)) if len(tab) else {"nodes": 0, "tris": 0}
+            nodes_total += c["nodes"]
+            tris_total += c["tris"]
+            # the oracle on the sub-grid: regenerate the rays from the GPU's own input records, brute force over all triangles
+            prev_s = src[sel_d].cpu().numpy()
+            got = dst[sel_d].cpu().numpy()
+            live_s = np.ones(len(sel), bool) if k == 0 else (prev_s[:, 14].view(np.uint32) != rt.MISS_ID)
+            c0 = time.perf_counter()
+            want_rays = oracle.trace_setup(prev_s[live_s], j.cam, 0 if k == 0 else 1)
+            oid, ot, _, _ = oracle.closest_hit(j.mesh.verts, j.mesh.faces, want_rays, threads=threads) if live_s.any() else (np.zeros(0, np.uint32),) * 4
+            cpu_secs += time.perf_counter() - c0
+            cpu_rays += int(live_s.sum())
+            gid, gt = got[live_s, 14].view(np.uint32), got[live_s, 15]
+            hit = oid != rt.MISS_ID
+            id_bad += int((gid != oid).sum()) + int((got[~live_s, 14].view(np.uint32) != rt.MISS_ID).sum())
+            t_bad += int((gt[hit].view(np.uint32) != ot[hit].view(np.uint32)).sum())
+            traced_total += traced
+            passes.append({"pass": k, "rays_traced": traced, "rays_hit": hits, "node_records": c["nodes"], "tri_records": c["tris"]})
+
+        chain(j, check)
+        per_scene.append({"model": j.model, "triangles": len(j.mesh.faces), "nodes": j.info["nodes4"], "passes": passes})
+
+    record_passes = len(jobs) * 5 * n
+    secs = ms_per_step * 1e-3
+    node_b, tri_b = jobs[0].info["node4_bytes"], jobs[0].info["tri_bytes"]
+    stream_b = 64 + 64 + 16       # per record pass: record in, record out, RGBA32F pixel
+    hbm = {"achieved": round(stream_b * record_passes / secs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "what": "compulsory streams of every record pass (terminated records are read and passed through too): 64 B in + 64 B out + 16 B pixel"}
+    hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBS, 4)
+    roofline = {"bound": "hbm", "achieved": hbm["achieved"], "peak": hbm["peak"], "unit": "GB/s", "frac": hbm["frac"], "traffic": None,
+                "resources": {"hbm": hbm}, "kernel": "ClosestHitKernel<4, true, kModeTrace>", "kernel_ms": round(dev_ms / (len(jobs) * 5), 4),
+                "algorithmic": {"stream_bytes_per_record_pass": stream_b,
+                                "bytes_per_traced_ray": round((stream_b * record_passes + nodes_total * node_b + tris_total * tri_b) / max(1, traced_total), 1),
+                                "node_records_per_traced_ray": round(nodes_total / max(1, traced_total), 3),
+                                "tri_records_per_traced_ray": round(tris_total / max(1, traced_total), 3),
+                                "node_bytes": node_b, "tri_bytes": tri_b}}
+    cpu = {"value": round(cpu_rays / max(cpu_secs, 1e-9) / 1e6, 6), "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "sample": f"stride-{sgrid} sub-grid of every pass of both scenes ({cpu_rays} traced rays): ray regeneration from the GPU's own input "
+                     "records + brute-force closest hit over all triangles",
+           "seconds": round(cpu_secs, 2), "id_mismatches_vs_gpu": id_bad, "t_bit_mismatches_vs_gpu": t_bad}
+    line = {
+        "metric": "closest-hit Mrays/s", "value": round(traced_total / secs / 1e6, 1), "unit": "Mrays/s", "n_gpus": 1,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"cube_mirror_test.obj + teapot.obj {W}x{H}: primary pass + 4 reflection passes each (full trace kernel)",
+                   "name": "mirror5", "rays_traced_per_step": traced_total, "record_passes_per_step": record_passes,
+                   "record_passes_Mrecords_per_s": round(record_passes / secs / 1e6, 1), "loader": "reference",
+                   "bvh": a.bvh, "bvh_width": 4, "hit_record": "64B RayIntersection + 16B RGBA32F pixel",
+                   "camera": "cube_mirror_test: reference pinhole from the +z side (rotation 2.6 rad about y); teapot: framed from -z",
+                   "scenes": per_scene},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line), flush=True)
+    for j in jobs:
+        j.scene.close()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -163,6 +319,11 @@ def main():
     red_dev = "cuda" if a.backend == "nccl" else "cpu"   # where the scalar reductions below live
     workload = a.workload or ("dragon1080" if world == 1 else "tiles4k")
     sharded = workload == "tiles4k"
+    if workload == "mirror5":
+        if world != 1:
+            raise SystemExit("--workload mirror5 runs on one GPU")
+        run_mirror5(a, local)
+        return
 
     model, W, H = WORKLOADS[workload]
     mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "reference" if workload == "mirror5" else "tolerant")
