@@ -15,7 +15,7 @@ HIPFLAGS = -std=c++17 -O3 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fhip-f
            -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -Wall -Wno-unused-parameter -Iinclude $(EXTRA_HIPFLAGS)
 
 HOST_SRCS = obj_loader centroid_bvh sah_bvh raygen flatten framebuffer
-HIP_SRCS = trace_kernels flatten_device capi
+HIP_SRCS = trace_kernels flatten_device capi multi_gpu
 HOST_OBJS = $(foreach s,$(HOST_SRCS),$(BUILD)/$(s).o)
 HIP_OBJS = $(foreach s,$(HIP_SRCS),$(BUILD)/$(s).o)
 HDRS = $(wildcard $(CS)/*.h) $(wildcard include/*.h)
@@ -31,7 +31,7 @@ $(BUILD)/%.o: $(CS)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(OUT): $(HOST_OBJS) $(HIP_OBJS)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -Wl,-rpath,$(ROCM)/lib -lpthread
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -Wl,-rpath,$(ROCM)/lib -lpthread -ldl
 
 tools/rt_headless: tools/rt_headless.cpp $(OUT) $(HDRS)
 	$(CXX) -std=c++17 -O2 -Iinclude -I$(ROCM)/include -D__HIP_PLATFORM_AMD__ -o $@ tools/rt_headless.cpp -Lraytrace_amd -lrtamd -L$(ROCM)/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../raytrace_amd' -Wl,-rpath,$(ROCM)/lib

@@ -81,13 +81,14 @@ def parse():
     ap.add_argument("--cpu-stride", type=int, default=4, help="sub-grid stride (both axes) of the CPU baseline sample")
     ap.add_argument("--tile", type=int, default=64, help="tiles4k: side of the squares dealt to the ranks (multiple of 8)")
     ap.add_argument("--assign", default="cost", choices=["cost", "roundrobin"], help="tiles4k: how squares are dealt to ranks")
-    ap.add_argument("--gather", default="hits16", choices=["hits16", "bgra8"],
-                    help="tiles4k: what crosses the GPUs into rank 0's framebuffer: the 16-byte {id,t,u,v} hit of every pixel, or its "
-                         "shaded 8-bit BGRA pixel (the full trace step + rt_pack_bgra8: a quarter of the bytes)")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[0, 1, 2],
-                    help="tiles4k: 1 = the exchange of a frame runs beside the trace of the next one (two frames in flight, "
-                         "double-buffered); 2 = also on two streams, so the traces of the two frames overlap; "
-                         "0 = trace, exchange, scatter one after the other")
+    ap.add_argument("--gather", default="hits8", choices=["hits8", "hits16", "bgra8"],
+                    help="tiles4k: what crosses the GPUs into rank 0's framebuffer: the 8-byte {id,t} of every pixel (default), its 16-byte "
+                         "{id,t,u,v} hit, or its shaded 8-bit BGRA pixel (the full trace step + rt_pack_bgra8)")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[0, 1, 2, 3, 4],
+                    help="tiles4k: frames in flight, each on a stream of its own (trace, exchange and scatter of a frame on its stream, so "
+                         "the exchange of a frame runs beside the traces of the next ones); 0 = one frame at a time on the caller's stream")
+    ap.add_argument("--scene-per-stream", type=int, default=0,
+                    help="tiles4k: 1 = every frame in flight has a scene object of its own (own launch-order tables and side stream)")
     ap.add_argument("--image-hint", type=int, default=1, help="declare the ray array as a W-wide image (8x8 tiles per wave)")
     ap.add_argument("--raygen", default="table", choices=["table", "device"],
                     help="table: rays are a RayIntersection array resident in HBM (the reference's interface); device: "
@@ -296,6 +297,349 @@ def run_mirror5(a, local):
         j.scene.close()
 
 
+def run_tiles4k(a, rank, world, local, dist, red_dev):
+    """--workload tiles4k (the default with N > 1): ONE dragon 3840x2160 frame per step, strong scaling.  The image is cut into
+    squares and dealt to the ranks by measured traversal cost (rt_shard_plan); every rank traces its squares; the records
+    cross into rank 0's framebuffer in the step (rt_gather_scatter: grouped RCCL point-to-point into rank 0, then the device
+    scatter).  Several frames are in flight, each on a stream of its own, so the exchange of a frame runs beside the traces of
+    the next ones.  Everything between the rays and the framebuffer goes through the library's C ABI."""
+    model, W, H = WORKLOADS["tiles4k"]
+    assert a.tile % 8 == 0
+    mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "tolerant")
+    bvh = rt.BVH(mesh, a.bvh)
+    def new_scene():
+        sc = rt.Scene(mesh, bvh, device=local, width=4)
+        sc.set_param("width", 4)
+        sc.set_param("feedback", a.feedback)
+        for kv in a.param:
+            k, v = kv.split("=")
+            sc.set_param(k, int(v))
+        return sc
+    scene = new_scene()
+    more_scenes = []
+    info = scene.info()
+    box = bvh.root_box
+    origin = rt.frame_camera(box, W, H)
+    null_stream = torch.cuda.current_stream().cuda_stream
+    extra = {}
+    # every rank measures the same per-tile costs with one untimed pass of its own (deterministic wave iteration counts), so
+    # all ranks derive the same plan without exchanging anything
+    units = scene.unit_costs_primary(W, H, origin)
+    R = a.share_of if (a.share_of > 1 and world == 1) else world
+    plan = rt.ShardPlan(W, H, a.tile, R, units if a.assign == "cost" else None)
+    me = rank if R == world else 0
+    if R != world:
+        extra["rehearsal"] = f"rank 0's share of {a.share_of} ranks on one GPU, no exchange; value counts only those rays"
+    full_h = rt.primary_rays(W, H, origin)
+    rays_h = full_h[plan.ray_indices(me)]
+    n_local = len(rays_h)
+    rays_d = torch.from_numpy(rays_h).cuda()
+    hint = a.tile if (a.image_hint and W % a.tile == 0) else 0
+    scene.set_param("image_width", hint)     # a rank's rays are its squares stacked: an image one square wide, so waves keep 8x8 blocks
+    from raytrace_amd import tiles as tl
+    sq_costs = tl.tile_costs_from_units(units, W, H, a.tile)
+    extra["tile_assignment"] = {"squares": len(plan.tile_order), "side": a.tile, "by": a.assign, "planned_by": "rt_shard_plan",
+                                "modelled_max_over_mean_cost": round(tl.balance([t.astype(np.int64) for t in plan.tiles], sq_costs), 4),
+                                "round_robin_would_be": round(tl.balance(tl.assign_tiles(len(plan.tile_order), R, None), sq_costs), 4)}
+    cam = np.eye(4, dtype=np.float32)
+    comm = None
+    if world > 1 and a.backend == "nccl":
+        idt = torch.zeros(128, dtype=torch.uint8, device=red_dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(rt.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        comm = rt.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local)
+
+    REC = {"hits16": 16, "hits8": 8, "bgra8": 4}
+    WHAT = {"hits16": "16 B {id,t,u,v}", "hits8": "8 B {id,t} (rt_pack_hits8)", "bgra8": "8-bit BGRA pixel (full trace step + rt_pack_bgra8)"}
+
+    def build(payload, frames_in_flight):
+        """Buffers and the step of the sharded frame for one kind of gathered record and one pipeline depth."""
+        rec_b = REC[payload]
+        NB = max(1, frames_in_flight)
+        streams = [torch.cuda.Stream() for _ in range(NB)] if frames_in_flight >= 1 else None
+
+        def raw(b):
+            return streams[b].cuda_stream if streams else null_stream
+
+        def records(nrec):
+            return torch.empty((nrec, rec_b // 4), dtype=torch.int32, device="cuda")
+
+        scn = [scene] * NB
+        if a.scene_per_stream and NB > 1:
+            while len(more_scenes) < NB - 1:
+                more_scenes.append(new_scene())
+                more_scenes[-1].set_param("image_width", hint)
+            scn = [scene] + more_scenes[:NB - 1]
+        root = me == 0
+        if R == world:
+            first_record = plan.first_record
+            ids_h, first_h = plan.scatter_tables()
+        else:     # rehearsal: only rank 0's squares exist
+            first_record = np.array([0, n_local], np.uint64)
+            ids_h = np.ascontiguousarray(plan.tiles[0])
+            first_h = np.zeros(len(ids_h), np.uint32)
+            rt._check(rt.lib.rt_shard_ray_indices(W, H, a.tile, rt._ptr(ids_h), len(ids_h), 0, None, rt._ptr(first_h)))
+        total = int(first_record[-1])
+        gather = [records(total) for _ in range(NB)] if root else [None] * NB
+        fbs = [records(W * H) for _ in range(NB)] if root else [None] * NB
+        ids_d = torch.from_numpy(ids_h.astype(np.int32)).cuda() if root else None
+        first_d = torch.from_numpy(first_h.astype(np.int32)).cuda() if root else None
+        lo = int(first_record[me])
+        mine = [g[lo:lo + n_local] for g in gather] if root else [records(n_local) for _ in range(NB)]   # root traces into its slice
+        h16 = [torch.empty((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(NB)] if payload == "hits8" else None
+        rgba = [torch.empty((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(NB)] if payload == "bgra8" else None
+        host_in = [torch.empty((int(first_record[r + 1] - first_record[r]), rec_b // 4), dtype=torch.int32) for r in range(world)] \
+            if (world > 1 and comm is None and root) else None
+        state = types.SimpleNamespace(frame=0, last=None)
+
+        def trace_into(b):
+            q = raw(b)
+            if payload == "bgra8":   # the full trace step (identity camera) writes the RGBA32F pixel; packed to 8-bit BGRA for the wire
+                scn[b].trace_pass(rays_d.data_ptr(), None, rgba[b].data_ptr(), n_local, cam, 0, q)
+                rt.pack_bgra8(local, rgba[b].data_ptr(), n_local, mine[b].data_ptr(), q)
+            elif payload == "hits8":
+                scn[b].intersect_async(rays_d.data_ptr(), n_local, None, h16[b].data_ptr(), q)
+                rt.pack_hits8(local, h16[b].data_ptr(), n_local, mine[b].data_ptr(), q)
+            else:
+                scn[b].intersect_async(rays_d.data_ptr(), n_local, None, mine[b].data_ptr(), q)
+
+        def exchange(b):
+            q = raw(b)
+            if world > 1 and comm is None:
+                # rehearsal backend (gloo): through host memory, synchronously; the scatter is still the library's
+                ctx = torch.cuda.stream(streams[b]) if streams else contextlib.nullcontext()
+                with ctx:
+                    if root:
+                        for r in range(1, world):
+                            dist.recv(host_in[r], src=r)
+                            gather[b][int(first_record[r]):int(first_record[r + 1])].copy_(host_in[r])
+                    else:
+                        dist.send(mine[b].cpu(), dst=0)
+                if root:
+                    rt.gather_scatter(None, 0, 1, 0, local, gather[b].data_ptr(), gather[b].data_ptr(), np.array([0, total], np.uint64), rec_b,
+                                      ids_d.data_ptr(), first_d.data_ptr(), len(ids_h), a.tile, W, H, fbs[b].data_ptr(), q)
+            else:
+                nr = world if R == world else 1
+                rt.gather_scatter(comm, me if nr > 1 else 0, nr, 0, local, mine[b].data_ptr(), gather[b].data_ptr() if root else None, first_record, rec_b,
+                                  ids_d.data_ptr() if root else None, first_d.data_ptr() if root else None, len(ids_h) if root else 0,
+                                  a.tile, W, H, fbs[b].data_ptr() if root else None, q)
+            if root:
+                state.last = fbs[b]
+
+        def step():
+            b = state.frame % NB
+            state.frame += 1
+            trace_into(b)
+            exchange(b)
+
+        def flush():
+            if streams:
+                cur = torch.cuda.current_stream()
+                for st in streams:
+                    cur.wait_stream(st)
+
+        def start():      # work enqueued on the current stream before the loop (warm-up, fills) comes first
+            if streams:
+                cur = torch.cuda.current_stream()
+                for st in streams:
+                    st.wait_stream(cur)
+        return types.SimpleNamespace(payload=payload, rec_b=rec_b, NB=NB, nstreams=len(streams) if streams else 1, step=step, flush=flush, start=start,
+                                     trace_into=trace_into, exchange=exchange, fbs=fbs, state=state, first_record=first_record)
+
+    def run(sh, steps, warm):
+        for _ in range(warm):
+            sh.step()
+        sh.flush()
+        torch.cuda.synchronize()
+        sh.start()
+        w, _ = timed(dist, steps, sh.step, sh.flush)
+        t = torch.tensor([w], dtype=torch.float64, device=red_dev)
+        if dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) * 1e3 / max(1, steps)
+
+    sh = build(a.gather, a.pipeline)
+    ms_per_step = run(sh, a.steps, a.warmup)
+    # what the host spends enqueueing a step (nothing waited for): the floor of a step however fast the GPU is
+    torch.cuda.synchronize()
+    c0 = time.perf_counter()
+    for _ in range(50):
+        sh.step()
+    extra["host_enqueue_us_per_step"] = round((time.perf_counter() - c0) / 50 * 1e6, 1)
+    sh.flush()
+    torch.cuda.synchronize()
+    n_total = n_local
+    if dist:
+        nn = torch.tensor([n_local], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        n_total = int(nn.item())
+    mrays = n_total / (ms_per_step * 1e-3) / 1e6
+
+    # the parts of the step on their own: trace only (slowest rank), exchange only
+    sub = max(5, a.steps // 4)
+    solo = build(a.gather, 0)
+    w_tr, _ = timed(dist, sub, lambda: solo.trace_into(0))
+    w_ex, _ = timed(dist, sub, lambda: solo.exchange(0))
+    parts = torch.tensor([w_tr / sub * 1e3, w_ex / sub * 1e3], dtype=torch.float64, device=red_dev)
+    if dist:
+        dist.all_reduce(parts, op=dist.ReduceOp.MAX)
+    trace_ms = float(parts[0])
+    extra["trace_only_ms"] = round(trace_ms, 4)
+    extra["gather_and_scatter_ms"] = round(float(parts[1]), 4)
+    extra["gather_bytes_into_rank0"] = int((int(sh.first_record[-1]) - int(plan.first_record[1] - plan.first_record[0])) * sh.rec_b) if R == world else 0
+    extra["gathered_record"] = WHAT[a.gather]
+    extra["frames_in_flight"] = sh.NB
+    extra["streams"] = sh.nstreams
+    extra["exchange"] = ("rt_gather_scatter over an RCCL communicator made by rt_comm_create" if comm is not None else
+                         ("rt_gather_scatter, one rank" if world == 1 else "gloo through host memory (rehearsal) + rt_gather_scatter for the scatter"))
+    if a.pipeline >= 1:
+        ms_1 = run(solo, sub, 2)
+        extra["same_steps_one_frame_at_a_time"] = {"ms_per_step": round(ms_1, 4), "value": round(n_total / (ms_1 * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
+    del solo
+
+    if world > 1:
+        # the whole frame on ONE GPU of this job (rank 0 alone, the others wait): the strong-scaling reference point
+        if rank == 0:
+            full_d = torch.from_numpy(full_h).cuda()
+            one16 = torch.empty((W * H, 4), dtype=torch.float32, device="cuda")
+            one_out = torch.empty((W * H, sh.rec_b // 4), dtype=torch.int32, device="cuda")
+            one_rgba = torch.empty((W * H, 4), dtype=torch.float32, device="cuda") if a.gather == "bgra8" else None
+            scene.set_param("image_width", W)
+
+            def one_gpu_frame():
+                if a.gather == "bgra8":
+                    scene.trace_pass(full_d.data_ptr(), None, one_rgba.data_ptr(), W * H, cam, 0, null_stream)
+                    rt.pack_bgra8(local, one_rgba.data_ptr(), W * H, one_out.data_ptr(), null_stream)
+                elif a.gather == "hits8":
+                    scene.intersect_async(full_d.data_ptr(), W * H, None, one16.data_ptr(), null_stream)
+                    rt.pack_hits8(local, one16.data_ptr(), W * H, one_out.data_ptr(), null_stream)
+                else:
+                    scene.intersect_async(full_d.data_ptr(), W * H, None, one_out.data_ptr(), null_stream)
+            for _ in range(10):
+                one_gpu_frame()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(sub):
+                one_gpu_frame()
+            torch.cuda.synchronize()
+            one_ms = (time.perf_counter() - t0) / sub * 1e3
+            extra["one_gpu_same_frame"] = {"ms_per_step": round(one_ms, 4), "value": round(W * H / (one_ms * 1e-3) / 1e6, 1),
+                                           "unit": "Mrays/s", "speedup_of_this_job": round(one_ms / ms_per_step, 3)}
+            scene.set_param("image_width", hint)
+            for fb in sh.fbs:
+                fb.fill_(-1)             # every frame of the loop is the same image: only a wiped framebuffer proves this step's scatter
+            torch.cuda.synchronize()
+        sh.start()
+        sh.step()
+        sh.flush()
+        torch.cuda.synchronize()
+        if rank == 0:
+            extra["framebuffer_equals_one_gpu"] = bool(torch.equal(sh.state.last, one_out))
+            del full_d, one16, one_out, one_rgba
+        dist.barrier()
+        # the same sharded frame with the 16-byte hit as the gathered record (twice the bytes on the links)
+        if a.gather != "hits16":
+            alt = build("hits16", a.pipeline)
+            ms_a = run(alt, sub, max(2, a.warmup // 4))
+            extra["same_frame_gathered_as"] = {"record": WHAT["hits16"], "ms_per_step": round(ms_a, 4), "value": round(W * H / (ms_a * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
+            del alt
+        # weak scaling beside it: every rank traces its own 1920x1080 dragon frame (64-byte records), no exchange
+        Wf, Hf = 1920, 1080
+        of = rt.frame_camera(box, Wf, Hf)
+        of[0] += rank * 0.01 * float(box[1, 0] - box[0, 0])
+        rays_f = torch.from_numpy(rt.primary_rays(Wf, Hf, of)).cuda()
+        hits_f = torch.empty((Wf * Hf, 16), dtype=torch.float32, device="cuda")
+        scene.set_param("image_width", Wf)
+
+        def step_f():
+            scene.intersect_async(rays_f.data_ptr(), Wf * Hf, hits_f.data_ptr(), None, null_stream)
+        for _ in range(a.warmup):
+            step_f()
+        w_f, _ = timed(dist, a.steps, step_f)
+        tf = torch.tensor([w_f], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+        ms_f = float(tf.item()) * 1e3 / max(1, a.steps)
+        extra["frame_parallel_weak_scaling"] = {"workload": "dragon.obj 1920x1080 primary rays, one frame per rank, no exchange",
+                                                "ms_per_step": round(ms_f, 4), "value": round(world * Wf * Hf / (ms_f * 1e-3) / 1e6, 1),
+                                                "unit": "Mrays/s", "scaling": "weak"}
+        scene.set_param("image_width", hint)
+        del rays_f, hits_f
+
+    if rank == 0:
+        n_count = min(n_local, 1 << 24)
+        cnt = scene.count_fetches_device(rays_d.data_ptr(), n_count)
+        n_node, n_tri = cnt["nodes"] / cnt["rays"], cnt["tris"] / cnt["rays"]
+        out_b = 16
+        stream_b = 64 + out_b
+        trav_b = n_node * info["node4_bytes"] + n_tri * info["tri_bytes"]
+        secs = trace_ms * 1e-3          # the roofline figures are the trace kernel's, not the exchange's
+        hbm = {"achieved": round(stream_b * n_local / secs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "what": f"compulsory streams of this rank's trace launch: 64 B ray in + {out_b} B out"}
+        hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBS, 4)
+        roofline = {"bound": "hbm", "achieved": hbm["achieved"], "peak": hbm["peak"], "unit": hbm["unit"], "frac": hbm["frac"], "traffic": None,
+                    "resources": {"hbm": hbm}, "kernel": "ClosestHitKernel", "kernel_ms": round(trace_ms, 4),
+                    "algorithmic": {"bytes_per_ray": round(stream_b + trav_b, 1), "stream_bytes_per_ray": stream_b,
+                                    "node_records_per_ray": round(n_node, 3), "tri_records_per_ray": round(n_tri, 3),
+                                    "node_bytes": info["node4_bytes"], "tri_bytes": info["tri_bytes"],
+                                    "hit_fraction": round(cnt["rays_hit"] / cnt["rays"], 4)}}
+        cpu = cpu_bvh = None
+        if world == 1 and R == 1 and not a.no_cpu_baseline and a.gather != "bgra8":
+            import oracle  # the CPU checker, used here only as the timed baseline
+            for fb in sh.fbs:
+                fb.fill_(-1)            # wiped first: the check below must see THIS step's gather and scatter
+            torch.cuda.synchronize()
+            sh.start()
+            sh.step()
+            sh.flush()
+            torch.cuda.synchronize()
+            fb = sh.state.last.cpu().numpy()
+            threads = oracle.default_threads()
+            sgr = a.cpu_stride
+            sel = (np.arange(0, H, sgr)[:, None] * W + np.arange(0, W, sgr)[None, :]).reshape(-1)
+            c0 = time.perf_counter()
+            oid, ot, _, _ = oracle.closest_hit(mesh.verts, mesh.faces, full_h[sel], threads=threads)
+            cdt = time.perf_counter() - c0
+            hit = oid != rt.MISS_ID
+            gid, gt = fb[sel, 0].view(np.uint32), fb[sel, 1].view(np.float32)
+            cpu = {"value": round(len(sel) / cdt / 1e6, 6), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                   "sample": f"stride-{sgr} sub-grid of the {W}x{H} ray set ({len(sel)} rays x {len(mesh.faces)} triangles, brute force)",
+                   "seconds": round(cdt, 2), "id_mismatches_vs_gpu": int((gid != oid).sum()),
+                   "t_bit_mismatches_vs_gpu": int((gt[hit].view(np.uint32) != ot[hit].view(np.uint32)).sum())}
+            c0 = time.perf_counter()
+            oid, ot, _, _ = oracle.closest_hit_bvh(mesh.verts, mesh.faces, bvh.nodes, full_h, threads=threads)
+            cdt = time.perf_counter() - c0
+            hit = oid != rt.MISS_ID
+            gid, gt = fb[:, 0].view(np.uint32), fb[:, 1].view(np.float32)
+            cpu_bvh = {"value": round(len(full_h) / cdt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                       "sample": f"all {len(full_h)} rays, closest hit through the same CentroidBVH tree (oracle tree walk), against the gathered framebuffer",
+                       "seconds": round(cdt, 2), "id_mismatches_vs_gpu": int((gid != oid).sum()),
+                       "t_bit_mismatches_vs_gpu": int((gt[hit].view(np.uint32) != ot[hit].view(np.uint32)).sum())}
+        line = {
+            "metric": "closest-hit Mrays/s", "value": round(mrays, 1), "unit": "Mrays/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{model} {W}x{H} primary rays, image squares sharded over {world} GPU(s), framebuffer gathered to rank 0",
+                       "name": "tiles4k", "rays_per_gpu": n_local, "rays_total": n_total, "triangles": len(mesh.faces), "loader": "tolerant",
+                       "bvh": a.bvh, "bvh_width": 4, "nodes": info["nodes4"], "hit_record": WHAT[a.gather],
+                       "rays": "RayIntersection table resident in HBM",
+                       "parallelism": f"{world} x one process per GPU, cost-balanced image squares (rt_shard_plan) + RCCL gather into rank 0 and "
+                                      f"device scatter (rt_gather_scatter), {sh.NB} frame(s) in flight"},
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_bvh": cpu_bvh,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+    if comm is not None:
+        comm.close()
+    for sc in more_scenes:
+        sc.close()
+    scene.close()
+    if dist:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -323,6 +667,9 @@ def main():
         if world != 1:
             raise SystemExit("--workload mirror5 runs on one GPU")
         run_mirror5(a, local)
+        return
+    if sharded:
+        run_tiles4k(a, rank, world, local, dist, red_dev)
         return
 
     model, W, H = WORKLOADS[workload]

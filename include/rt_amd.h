@@ -265,6 +265,61 @@ int rt_scatter_tiles(int device, const void *src_dev, size_t src_records, const 
  * the bytes when a framebuffer has to cross GPUs.  Device pointers of `device`, enqueued on `stream`. */
 int rt_pack_bgra8(int device, const float *rgba_dev, size_t n, void *bgra_dev, void *stream);
 
+/* 16-byte {id, t, u, v} hits -> 8-byte {id, t} records: what a framebuffer of hits needs on the wire between GPUs (the
+ * barycentrics follow from the ray and t wherever the frame is shaded).  No counterpart in the reference.  Device pointers
+ * of `device`, enqueued on `stream`. */
+int rt_pack_hits8(int device, const void *hits16_dev, size_t n, void *hits8_dev, void *stream);
+
+/* The reference's display pass on the device, so that a frame leaves the GPU once, as 8-bit pixels: layer 0 (the primary
+ * pass's RGBA32F pixels) drawn opaque, layer 1 (the reflection pass's; NULL = none) blended over it with
+ * glBlendFunc(GL_SRC_ALPHA, GL_ONE_MINUS_DST_ALPHA) (render_client/img_main.cpp:434,512-526):
+ * out = layer1 * layer1.a + layer0 * (1 - layer0.a) per channel.  Writes the blended RGBA32F pixels (rgba_out_dev, nullable)
+ * and/or their 8-bit BGRA form as rt_pack_bgra8 makes it (bgra_out_dev, nullable).  Enqueued on `stream`. */
+int rt_composite_layers(int device, const float *layer0_rgba_dev, const float *layer1_rgba_dev, size_t n, float *rgba_out_dev,
+                        void *bgra_out_dev, void *stream);
+
+/* ------------------------------------------------------------------ one frame on several GPUs (one process per GPU)
+ * The reference renders one image on one device; its only hint of tiling is the commented-out four-offset NDRange of
+ * render_client/img_main.cpp:464-478.  Here the image is cut into tile x tile squares (edge squares smaller, numbered
+ * row-major), every rank traces the squares dealt to it and the records are gathered into one rank's framebuffer.
+ *
+ * rt_shard_plan deals the squares to `nranks` ranks.  unit_costs (nullable) is the per-8x8-tile cost table of
+ * rt_scene_unit_costs / _primary for this image ((ceil(height/8) x ceil(width/8)), row-major; tile must then be a
+ * multiple of 8): squares go costliest first to the rank with the least cost so far, so the ranks finish together
+ * whatever the silhouette looks like; the table is deterministic, so every rank derives the same plan without talking.
+ * Without it the squares are dealt round-robin.  Re-planning from fresh costs every few frames follows a moving camera.
+ * Outputs: tile_order[tiles_x * tiles_y] = the squares rank after rank, each rank's in the order dealt (costliest first);
+ * rank_first_tile[nranks + 1] = where each rank's squares start in tile_order; rank_first_record[nranks + 1] = where each
+ * rank's records (pixels, square after square, row-major inside a square) start in the gather buffer. */
+int rt_shard_plan(int width, int height, int tile, int nranks, const uint32_t *unit_costs, uint32_t *tile_order,
+                  uint64_t *rank_first_tile, uint64_t *rank_first_record);
+/* For a list of squares: ray_index[] (nullable) = the row-major pixel / ray index (i + j * width) of every record, square
+ * after square; tile_first[i] (nullable) = first_record + position of square i's first record -- the table
+ * rt_scatter_tiles takes. */
+int rt_shard_ray_indices(int width, int height, int tile, const uint32_t *tile_ids, size_t ntiles, uint32_t first_record,
+                         uint32_t *ray_index, uint32_t *tile_first);
+
+/* Communicator of the job: a thin face of RCCL (ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy), loaded on first
+ * use.  One rank makes the id, hands its RT_COMM_ID_BYTES bytes to the others by any means, every rank calls
+ * rt_comm_create with its own device current; nranks = 1 is valid.  *comm_out is an ncclComm_t: a caller that already
+ * holds one passes that to rt_gather_scatter instead. */
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(uint8_t id_out[RT_COMM_ID_BYTES]);
+int rt_comm_create(const uint8_t id[RT_COMM_ID_BYTES], int nranks, int rank, int device, void **comm_out);
+void rt_comm_destroy(void *comm);
+
+/* The exchange step of a sharded frame, enqueued on `stream` of every rank (call it on all ranks, like a collective):
+ * every rank but `root` sends its records (mine_dev, rank_first_record[rank + 1] - rank_first_record[rank] of them,
+ * record_bytes each) to root; root receives rank r's into gather_dev + rank_first_record[r] * record_bytes -- one grouped
+ * RCCL call, a send/receive pair per peer, so root's xGMI links all carry their share at once (point to point, no ring)
+ * -- and then scatters the square-major gather buffer into the row-major framebuffer with rt_scatter_tiles (tile_ids_dev /
+ * tile_first_dev: all ranks' squares as rt_shard_plan / rt_shard_ray_indices list them, root only).  Root's own records
+ * may already sit in its slice of gather_dev (mine_dev pointing there: no copy).  nranks = 1 moves nothing between GPUs
+ * and needs no communicator.  Replaces nothing in the reference (it has no multi-device path). */
+int rt_gather_scatter(void *comm, int rank, int nranks, int root, int device, const void *mine_dev, void *gather_dev,
+                      const uint64_t *rank_first_record, size_t record_bytes, const uint32_t *tile_ids_dev, const uint32_t *tile_first_dev,
+                      size_t ntiles, int tile, int width, int height, void *framebuffer_dev, void *stream);
+
 /* Diagnostic: runs the instrumented kernel once over n device-resident rays and returns, per wave of
  * 64 rays (or per 8x8 tile with the image hint), records[4*w..4*w+3] = {start, end in 100 MHz ticks,
  * HW_ID register, XCC_ID register}.  capacity is in uint64 elements. */

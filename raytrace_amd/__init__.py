@@ -101,6 +101,14 @@ def _load():
         "rt_scene_unit_costs_primary": (i32, [vp, i32, i32, C.POINTER(C.c_float), vp, sz, C.POINTER(sz)]),
         "rt_scatter_tiles": (i32, [i32, vp, sz, vp, vp, sz, i32, i32, i32, sz, vp, vp]),
         "rt_pack_bgra8": (i32, [i32, vp, sz, vp, vp]),
+        "rt_pack_hits8": (i32, [i32, vp, sz, vp, vp]),
+        "rt_composite_layers": (i32, [i32, vp, vp, sz, vp, vp, vp]),
+        "rt_shard_plan": (i32, [i32, i32, i32, i32, vp, vp, vp, vp]),
+        "rt_shard_ray_indices": (i32, [i32, i32, i32, vp, sz, u32, vp, vp]),
+        "rt_comm_unique_id": (i32, [vp]),
+        "rt_comm_create": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
+        "rt_comm_destroy": (None, [vp]),
+        "rt_gather_scatter": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, sz, vp, vp, sz, i32, i32, i32, vp, vp]),
         "rt_scene_wave_timeline": (i32, [vp, vp, sz, vp, sz]),
         "rt_scene_wave_model": (i32, [vp, vp, sz, u32, u32, sz, i32, C.POINTER(u64)]),
         "rt_debug_tri_batch": (i32, [i32, vp, vp, sz, vp, vp, vp]),
@@ -368,6 +376,81 @@ def scatter_tiles(device, src_ptr, src_records, tile_ids_ptr, tile_first_ptr, nt
 def pack_bgra8(device, rgba_ptr, n, bgra_ptr, stream=0):
     """rt_pack_bgra8 on raw device addresses: n RGBA32F pixels -> n 8-bit BGRA pixels."""
     _check(lib.rt_pack_bgra8(device, _ptr(rgba_ptr), n, _ptr(bgra_ptr), C.c_void_p(stream) if stream else None))
+
+
+def pack_hits8(device, hits16_ptr, n, hits8_ptr, stream=0):
+    """rt_pack_hits8 on raw device addresses: n 16-byte {id,t,u,v} hits -> n 8-byte {id,t} records."""
+    _check(lib.rt_pack_hits8(device, _ptr(hits16_ptr), n, _ptr(hits8_ptr), C.c_void_p(stream) if stream else None))
+
+
+def composite_layers(device, layer0_ptr, layer1_ptr, n, rgba_out_ptr=None, bgra_out_ptr=None, stream=0):
+    """rt_composite_layers on raw device addresses (layer1_ptr None = one layer)."""
+    _check(lib.rt_composite_layers(device, _ptr(layer0_ptr), _ptr(layer1_ptr), n, _ptr(rgba_out_ptr), _ptr(bgra_out_ptr),
+                                   C.c_void_p(stream) if stream else None))
+
+
+class ShardPlan:
+    """rt_shard_plan: which squares of a width x height image (cut into tile x tile squares) each of `nranks` ranks traces.
+    tiles[r] = rank r's squares in the order dealt; first_record[r] = where its records start in the gather buffer."""
+
+    def __init__(self, width, height, tile, nranks, unit_costs=None):
+        self.width, self.height, self.tile, self.nranks = width, height, tile, nranks
+        tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
+        self.tile_order = np.zeros(tx * ty, np.uint32)
+        self.first_tile = np.zeros(nranks + 1, np.uint64)
+        self.first_record = np.zeros(nranks + 1, np.uint64)
+        costs = None if unit_costs is None else np.ascontiguousarray(unit_costs, dtype=np.uint32)
+        _check(lib.rt_shard_plan(width, height, tile, nranks, _ptr(costs), _ptr(self.tile_order), _ptr(self.first_tile), _ptr(self.first_record)))
+        self.tiles = [self.tile_order[int(self.first_tile[r]):int(self.first_tile[r + 1])] for r in range(nranks)]
+
+    def records(self, rank):
+        return int(self.first_record[rank + 1] - self.first_record[rank])
+
+    def ray_indices(self, rank):
+        """Row-major ray / pixel indices of rank's records, square after square."""
+        idx = np.zeros(self.records(rank), np.uint32)
+        t = np.ascontiguousarray(self.tiles[rank])
+        _check(lib.rt_shard_ray_indices(self.width, self.height, self.tile, _ptr(t), len(t), 0, _ptr(idx), None))
+        return idx
+
+    def scatter_tables(self):
+        """(tile ids, first record of each square in the gather buffer) for all ranks' squares: what rt_scatter_tiles takes."""
+        first = np.zeros(len(self.tile_order), np.uint32)
+        _check(lib.rt_shard_ray_indices(self.width, self.height, self.tile, _ptr(self.tile_order), len(self.tile_order), 0, None, _ptr(first)))
+        return self.tile_order.copy(), first
+
+
+class Comm:
+    """RCCL communicator made through the library (rt_comm_unique_id / rt_comm_create)."""
+
+    def __init__(self, comm_id, nranks, rank, device):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(comm_id))
+        _check(lib.rt_comm_create(buf, nranks, rank, device, C.byref(h)))
+        self._h, self.nranks, self.rank, self.device = h, nranks, rank, device
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        _check(lib.rt_comm_unique_id(buf))
+        return bytes(buf)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:
+            lib.rt_comm_destroy(h)
+
+    def __del__(self):
+        self.close()
+
+
+def gather_scatter(comm, rank, nranks, root, device, mine_ptr, gather_ptr, first_record, record_bytes, tile_ids_ptr, tile_first_ptr, ntiles,
+                   tile, width, height, framebuffer_ptr, stream=0):
+    """rt_gather_scatter: every rank's records to root over RCCL (one grouped point-to-point call), then the device scatter."""
+    fr = np.ascontiguousarray(first_record, dtype=np.uint64)
+    _check(lib.rt_gather_scatter(comm._h if comm is not None else None, rank, nranks, root, device, _ptr(mine_ptr), _ptr(gather_ptr), _ptr(fr),
+                                 record_bytes, _ptr(tile_ids_ptr), _ptr(tile_first_ptr), ntiles, tile, width, height, _ptr(framebuffer_ptr),
+                                 C.c_void_p(stream) if stream else None))
 
 
 def debug_tri_batch(tri, ray, device=0):

@@ -33,6 +33,13 @@ int FailHip(hipError_t e, const char *what)
   return Fail(RT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+}  // namespace
+
+// shared with multi_gpu.hip
+int RtFail(int code, const std::string &msg) { return Fail(static_cast<rt_status>(code), msg); }
+
+namespace {
+
 #define RT_HIP(call)                                   \
   do {                                                 \
     hipError_t e_ = (call);                            \

@@ -1,0 +1,314 @@
+// multi_gpu.hip -- one frame rendered by several GPUs, one process per GPU: which image squares a rank traces
+// (rt_shard_plan, rt_shard_ray_indices), the one exchange step of the path (rt_gather_scatter: every rank's records to
+// the root rank over RCCL, point to point, then the device scatter into the row-major framebuffer) and the small kernels
+// around it (8-byte hits for the wire, the two-layer composite of the reference's display pass).
+//
+// The reference renders one image on one device; its only hint of tiling is a commented-out split of the NDRange into
+// four offsets (render_client/img_main.cpp:464-478).  Nothing here is a translation of reference code.
+//
+// RCCL is loaded on first use (dlopen), so a one-GPU user of the library needs no communication library at all.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "device_scene.h"
+
+int RtFail(int code, const std::string &msg);   // capi.hip: sets rt_last_error()
+
+namespace {
+
+// ---- RCCL, bound at run time (names and signatures of rccl.h; the handful the exchange needs) ------------------------
+constexpr int kNcclUniqueIdBytes = 128;
+struct NcclUniqueId { char internal[kNcclUniqueIdBytes]; };
+typedef void *NcclComm;
+constexpr int kNcclUint8 = 1;   // ncclUint8
+
+struct Rccl {
+  void *lib = nullptr;
+  int (*GetUniqueId)(NcclUniqueId *) = nullptr;
+  int (*CommInitRank)(NcclComm *, int, NcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(NcclComm) = nullptr;
+  int (*Send)(const void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  std::string why;
+};
+
+Rccl *LoadRccl()
+{
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) {
+      r.why = std::string("cannot load librccl.so: ") + dlerror();
+      return;
+    }
+    auto sym = [&](const char *n) {
+      void *p = dlsym(r.lib, n);
+      if (!p && r.why.empty()) r.why = std::string("librccl.so lacks ") + n;
+      return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+  });
+  return &r;
+}
+
+int FailNccl(Rccl *r, int e, const char *what)
+{
+  return RtFail(RT_ERR_DEVICE, std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(e) : "RCCL error") + " (" + std::to_string(e) + ")");
+}
+
+struct DeviceScope {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceScope(int device)
+  {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceScope()
+  {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+// 16-byte {id, t, u, v} hits -> 8-byte {id, t}: what has to cross the GPUs for a framebuffer of hits (the barycentrics can be
+// recomputed from the ray and t wherever the frame is shaded).
+__global__ void __launch_bounds__(256) PackHits8Kernel(const uint4 *hits16, uint32_t n, uint2 *hits8)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4 h = hits16[i];
+  hits8[i] = make_uint2(h.x, h.y);
+}
+
+// The reference's display pass: layer 0 (the primary pass's pixels) drawn opaque, layer 1 (the reflection pass's) blended
+// over it with glBlendFunc(GL_SRC_ALPHA, GL_ONE_MINUS_DST_ALPHA) (render_client/img_main.cpp:434,512-526):
+// out = layer1 * layer1.a + layer0 * (1 - layer0.a), per channel, then 8-bit BGRA as rt_pack_bgra8 makes it.
+__global__ void __launch_bounds__(256) CompositeKernel(const float4 *layer0, const float4 *layer1, uint32_t n, float4 *rgba_out, uint32_t *bgra_out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = layer0[i];
+  float4 c = a;
+  if (layer1) {
+    const float4 b = layer1[i];
+    const float sa = b.w, da = 1.0f - a.w;
+    c = make_float4(b.x * sa + a.x * da, b.y * sa + a.y * da, b.z * sa + a.z * da, b.w * sa + a.w * da);
+  }
+  if (rgba_out) rgba_out[i] = c;
+  if (bgra_out) {
+    const uint32_t r = static_cast<uint32_t>(fminf(255.f, fmaxf(0.f, c.x * 255.f + 0.5f)));
+    const uint32_t g = static_cast<uint32_t>(fminf(255.f, fmaxf(0.f, c.y * 255.f + 0.5f)));
+    const uint32_t bl = static_cast<uint32_t>(fminf(255.f, fmaxf(0.f, c.z * 255.f + 0.5f)));
+    bgra_out[i] = bl | (g << 8) | (r << 16) | 0xFF000000u;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_shard_plan(int width, int height, int tile, int nranks, const uint32_t *unit_costs, uint32_t *tile_order,
+                  uint64_t *rank_first_tile, uint64_t *rank_first_record)
+{
+  if (width <= 0 || height <= 0 || tile <= 0 || nranks <= 0 || !tile_order || !rank_first_tile || !rank_first_record)
+    return RtFail(RT_ERR_INVALID, "bad shard plan arguments");
+  if (unit_costs && tile % 8 != 0) return RtFail(RT_ERR_INVALID, "with a cost table the squares must be made of whole 8x8 work units");
+  const uint32_t tx = (width + tile - 1) / tile, ty = (height + tile - 1) / tile, ntiles = tx * ty;
+  auto pixels = [&](uint32_t k) {
+    const uint32_t x0 = (k % tx) * tile, y0 = (k / tx) * tile;
+    return static_cast<uint64_t>(std::min<uint32_t>(tile, width - x0)) * std::min<uint32_t>(tile, height - y0);
+  };
+  std::vector<std::vector<uint32_t>> lists(nranks);
+  if (!unit_costs) {
+    for (uint32_t k = 0; k < ntiles; ++k) lists[k % nranks].push_back(k);   // round-robin
+  } else {
+    // the kernel's per-8x8-tile costs summed over each square; squares dealt costliest first, each to the rank with the least
+    // cost so far (ties: the lower rank); every square also carries a floor cost: its pixels are generated and stored whatever they hit
+    const uint32_t ux = (width + 7) / 8, uy = (height + 7) / 8, per = tile / 8;
+    std::vector<double> cost(ntiles, 0.0);
+    for (uint32_t j = 0; j < uy; ++j)
+      for (uint32_t i = 0; i < ux; ++i) cost[(j / per) * tx + i / per] += unit_costs[j * ux + i];
+    std::vector<uint32_t> order(ntiles);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    std::vector<double> load(nranks, 0.0);
+    for (uint32_t k : order) {
+      const int r = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
+      lists[r].push_back(k);
+      load[r] += cost[k] + 1.0;
+    }
+  }
+  uint64_t t = 0, rec = 0;
+  for (int r = 0; r < nranks; ++r) {
+    rank_first_tile[r] = t;
+    rank_first_record[r] = rec;
+    for (uint32_t k : lists[r]) {
+      tile_order[t++] = k;
+      rec += pixels(k);
+    }
+  }
+  rank_first_tile[nranks] = t;
+  rank_first_record[nranks] = rec;
+  return RT_OK;
+}
+
+int rt_shard_ray_indices(int width, int height, int tile, const uint32_t *tile_ids, size_t ntiles, uint32_t first_record,
+                         uint32_t *ray_index, uint32_t *tile_first)
+{
+  if (width <= 0 || height <= 0 || tile <= 0 || (!tile_ids && ntiles)) return RtFail(RT_ERR_INVALID, "bad shard arguments");
+  const uint32_t tx = (width + tile - 1) / tile, ty = (height + tile - 1) / tile;
+  uint64_t pos = 0;
+  for (size_t i = 0; i < ntiles; ++i) {
+    const uint32_t k = tile_ids[i];
+    if (k >= tx * ty) return RtFail(RT_ERR_INVALID, "square number out of range");
+    const uint32_t x0 = (k % tx) * tile, y0 = (k / tx) * tile;
+    const uint32_t w = std::min<uint32_t>(tile, width - x0), h = std::min<uint32_t>(tile, height - y0);
+    if (tile_first) tile_first[i] = first_record + static_cast<uint32_t>(pos);
+    if (ray_index)
+      for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) ray_index[pos + static_cast<uint64_t>(y) * w + x] = (y0 + y) * static_cast<uint32_t>(width) + x0 + x;
+    pos += static_cast<uint64_t>(w) * h;
+  }
+  return RT_OK;
+}
+
+int rt_pack_hits8(int device, const void *hits16_dev, size_t n, void *hits8_dev, void *stream)
+{
+  if (!hits16_dev || !hits8_dev) return RtFail(RT_ERR_INVALID, "null argument");
+  if (n == 0) return RT_OK;
+  if (n > 0xFFFFFFFFull) return RtFail(RT_ERR_INVALID, "more records than one launch addresses");
+  DeviceScope scope(device);
+  if (!scope.ok) return RtFail(RT_ERR_DEVICE, "hipSetDevice failed");
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(PackHits8Kernel, dim3((static_cast<uint32_t>(n) + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint4 *>(hits16_dev), static_cast<uint32_t>(n), static_cast<uint2 *>(hits8_dev));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return RtFail(RT_ERR_DEVICE, std::string("pack launch failed: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_composite_layers(int device, const float *layer0_rgba_dev, const float *layer1_rgba_dev, size_t n, float *rgba_out_dev,
+                        void *bgra_out_dev, void *stream)
+{
+  if (!layer0_rgba_dev || (!rgba_out_dev && !bgra_out_dev)) return RtFail(RT_ERR_INVALID, "null argument");
+  if (n == 0) return RT_OK;
+  if (n > 0xFFFFFFFFull) return RtFail(RT_ERR_INVALID, "more pixels than one launch addresses");
+  DeviceScope scope(device);
+  if (!scope.ok) return RtFail(RT_ERR_DEVICE, "hipSetDevice failed");
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(CompositeKernel, dim3((static_cast<uint32_t>(n) + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4 *>(layer0_rgba_dev), reinterpret_cast<const float4 *>(layer1_rgba_dev),
+                     static_cast<uint32_t>(n), reinterpret_cast<float4 *>(rgba_out_dev), static_cast<uint32_t *>(bgra_out_dev));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return RtFail(RT_ERR_DEVICE, std::string("composite launch failed: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+// ---- communicator: a thin face of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy -------------------------------
+int rt_comm_unique_id(uint8_t id_out[RT_COMM_ID_BYTES])
+{
+  if (!id_out) return RtFail(RT_ERR_INVALID, "null argument");
+  static_assert(RT_COMM_ID_BYTES == kNcclUniqueIdBytes, "id size");
+  Rccl *r = LoadRccl();
+  if (!r->why.empty()) return RtFail(RT_ERR_DEVICE, r->why);
+  NcclUniqueId id;
+  int e = r->GetUniqueId(&id);
+  if (e != 0) return FailNccl(r, e, "ncclGetUniqueId");
+  std::memcpy(id_out, id.internal, kNcclUniqueIdBytes);
+  return RT_OK;
+}
+
+int rt_comm_create(const uint8_t id[RT_COMM_ID_BYTES], int nranks, int rank, int device, void **comm_out)
+{
+  if (!id || !comm_out || nranks <= 0 || rank < 0 || rank >= nranks) return RtFail(RT_ERR_INVALID, "bad communicator arguments");
+  Rccl *r = LoadRccl();
+  if (!r->why.empty()) return RtFail(RT_ERR_DEVICE, r->why);
+  DeviceScope scope(device);
+  if (!scope.ok) return RtFail(RT_ERR_DEVICE, "hipSetDevice failed");
+  NcclUniqueId uid;
+  std::memcpy(uid.internal, id, kNcclUniqueIdBytes);
+  NcclComm comm = nullptr;
+  int e = r->CommInitRank(&comm, nranks, uid, rank);
+  if (e != 0) return FailNccl(r, e, "ncclCommInitRank");
+  *comm_out = comm;
+  return RT_OK;
+}
+
+void rt_comm_destroy(void *comm)
+{
+  Rccl *r = LoadRccl();
+  if (comm && r->CommDestroy) (void)r->CommDestroy(comm);
+}
+
+int rt_gather_scatter(void *comm, int rank, int nranks, int root, int device, const void *mine_dev, void *gather_dev,
+                      const uint64_t *rank_first_record, size_t record_bytes, const uint32_t *tile_ids_dev, const uint32_t *tile_first_dev,
+                      size_t ntiles, int tile, int width, int height, void *framebuffer_dev, void *stream)
+{
+  if (nranks <= 0 || rank < 0 || rank >= nranks || root < 0 || root >= nranks || !rank_first_record)
+    return RtFail(RT_ERR_INVALID, "bad rank arguments");
+  if (record_bytes == 0 || record_bytes % 4u != 0) return RtFail(RT_ERR_INVALID, "record size must be a multiple of 4 bytes");
+  if (nranks > 1 && !comm) return RtFail(RT_ERR_INVALID, "a communicator is needed for more than one rank");
+  const uint64_t mine = rank_first_record[rank + 1] - rank_first_record[rank];
+  if (mine && !mine_dev) return RtFail(RT_ERR_INVALID, "null record buffer");
+  if (rank == root && (!gather_dev || (ntiles && (!tile_ids_dev || !tile_first_dev || !framebuffer_dev))))
+    return RtFail(RT_ERR_INVALID, "the root rank needs the gather buffer, the square list and the framebuffer");
+  DeviceScope scope(device);
+  if (!scope.ok) return RtFail(RT_ERR_DEVICE, "hipSetDevice failed");
+  hipStream_t q = static_cast<hipStream_t>(stream);
+  if (nranks > 1) {
+    // One grouped call: the root posts a receive per peer and every peer one send, so all of the root's links carry their
+    // share at once (point to point, no ring: xGMI is a full mesh of links, and a ring would pass every byte over several).
+    Rccl *r = LoadRccl();
+    if (!r->why.empty()) return RtFail(RT_ERR_DEVICE, r->why);
+    int e = r->GroupStart();
+    if (e != 0) return FailNccl(r, e, "ncclGroupStart");
+    if (rank == root) {
+      for (int peer = 0; peer < nranks && e == 0; ++peer) {
+        const uint64_t cnt = rank_first_record[peer + 1] - rank_first_record[peer];
+        if (peer == root || cnt == 0) continue;
+        e = r->Recv(static_cast<char *>(gather_dev) + rank_first_record[peer] * record_bytes, cnt * record_bytes, kNcclUint8, peer, comm, q);
+      }
+    } else if (mine) {
+      e = r->Send(mine_dev, mine * record_bytes, kNcclUint8, root, comm, q);
+    }
+    const int e2 = r->GroupEnd();
+    if (e != 0) return FailNccl(r, e, "ncclSend/ncclRecv");
+    if (e2 != 0) return FailNccl(r, e2, "ncclGroupEnd");
+  }
+  if (rank != root) return RT_OK;
+  // the root's own records: traced straight into its slice of the gather buffer, or copied there now
+  char *own = static_cast<char *>(gather_dev) + rank_first_record[root] * record_bytes;
+  if (mine && mine_dev != own) {
+    hipError_t he = hipMemcpyAsync(own, mine_dev, mine * record_bytes, hipMemcpyDeviceToDevice, q);
+    if (he != hipSuccess) return RtFail(RT_ERR_DEVICE, std::string("hipMemcpyAsync: ") + hipGetErrorString(he));
+  }
+  if (ntiles == 0) return RT_OK;
+  return rt_scatter_tiles(device, gather_dev, rank_first_record[nranks], tile_ids_dev, tile_first_dev, ntiles, tile, width, height, record_bytes,
+                          framebuffer_dev, stream);
+}
+
+}  // extern "C"

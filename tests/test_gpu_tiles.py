@@ -125,3 +125,86 @@ def test_pixels_pack_to_bgra_and_scatter_as_4_byte_records(rt, gpu):
             rt.scatter_tiles(gpu, stacked.data_ptr(), W * H, ids_d.data_ptr(), first_d.data_ptr(), len(order), tile, W, H, 6, fb.data_ptr())
     finally:
         scene.close()
+
+
+def test_gather_scatter_entry_point_with_a_one_rank_communicator_and_logical_ranks(rt, gpu):
+    """rt_gather_scatter, the exchange step a C++ host calls.  (1) With a REAL RCCL communicator of one rank (made through
+    rt_comm_unique_id / rt_comm_create): the call moves nothing between GPUs, copies the rank's records into the gather
+    buffer and scatters.  (2) G logical ranks on one GPU: every rank's records are traced straight into its slice of the
+    gather buffer (what the root does for its own), then one call with nranks = 1 over the plan's tables scatters them.
+    Both framebuffers must equal the single-launch framebuffer byte for byte, for 16-byte hits and for 8-byte {id, t}
+    records packed by rt_pack_hits8."""
+    import torch
+    W, H, tile = 600, 360, 64
+    mesh = rt.Mesh.load_obj(os.path.join(MODELS, "bunny.obj"), "tolerant")
+    bvh = rt.BVH(mesh, "fixed")
+    origin = rt.frame_camera(bvh.root_box, W, H)
+    rays = rt.primary_rays(W, H, origin)
+    scene = rt.Scene(mesh, bvh, device=gpu, width=4)
+    scene.set_param("width", 4)
+    comm = rt.Comm(rt.Comm.unique_id(), 1, 0, gpu)
+    try:
+        rays_d = torch.from_numpy(rays).cuda()
+        want = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
+        scene.set_param("image_width", W)
+        scene.intersect_async(rays_d.data_ptr(), W * H, None, want.data_ptr())
+        torch.cuda.synchronize()
+        want8 = want[:, :2].contiguous()
+        units = scene.unit_costs_primary(W, H, origin)
+        scene.set_param("image_width", 0)
+        for G in (1, 3):
+            plan = rt.ShardPlan(W, H, tile, G, units)
+            ids, first = plan.scatter_tables()
+            ids_d, first_d = torch.from_numpy(ids.astype(np.int32)).cuda(), torch.from_numpy(first.astype(np.int32)).cuda()
+            gather = torch.full((W * H, 4), -3.0, dtype=torch.float32, device="cuda")
+            for r in range(G):
+                mine = torch.from_numpy(rays[plan.ray_indices(r)]).cuda()
+                scene.intersect_async(mine.data_ptr(), len(mine), None, gather.data_ptr() + int(plan.first_record[r]) * 16)
+                torch.cuda.synchronize()
+            fb = torch.full((W * H, 4), -5.0, dtype=torch.float32, device="cuda")
+            # the library sees ONE rank that owns every record (they are already in place: mine == its slice of the gather buffer)
+            whole = np.array([0, W * H], np.uint64)
+            rt.gather_scatter(comm if G == 1 else None, 0, 1, 0, gpu, gather.data_ptr(), gather.data_ptr(), whole, 16, ids_d.data_ptr(),
+                              first_d.data_ptr(), len(ids), tile, W, H, fb.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(fb.view(torch.int32), want.view(torch.int32)), G
+            # the same with a separate record buffer (copied into the gather buffer by the call) and the 8-byte payload
+            small = torch.empty((W * H, 2), dtype=torch.float32, device="cuda")
+            rt.pack_hits8(gpu, gather.data_ptr(), W * H, small.data_ptr())
+            gather8 = torch.full((W * H, 2), -3.0, dtype=torch.float32, device="cuda")
+            fb8 = torch.full((W * H, 2), -5.0, dtype=torch.float32, device="cuda")
+            rt.gather_scatter(comm, 0, 1, 0, gpu, small.data_ptr(), gather8.data_ptr(), whole, 8, ids_d.data_ptr(), first_d.data_ptr(), len(ids),
+                              tile, W, H, fb8.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(fb8.view(torch.int32), want8.view(torch.int32)), G
+        # argument errors
+        assert rt.lib.rt_gather_scatter(None, 0, 2, 0, gpu, None, None, None, 16, None, None, 0, tile, W, H, None, None) == -1
+    finally:
+        comm.close()
+        scene.close()
+
+
+def test_device_composite_equals_the_host_blend(rt, gpu):
+    """rt_composite_layers: the reference's two-layer display blend (render_client/img_main.cpp:434,512-526) on the device,
+    against the same arithmetic in numpy float32, for the blended RGBA32F pixels and their 8-bit BGRA form."""
+    import torch
+    rng = np.random.default_rng(3)
+    n = 100_003
+    l0 = rng.uniform(-0.2, 1.3, (n, 4)).astype(np.float32)
+    l1 = rng.uniform(-0.2, 1.3, (n, 4)).astype(np.float32)
+    a, b = torch.from_numpy(l0).cuda(), torch.from_numpy(l1).cuda()
+    out = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+    pix = torch.zeros(n, dtype=torch.int32, device="cuda")
+    rt.composite_layers(gpu, a.data_ptr(), b.data_ptr(), n, out.data_ptr(), pix.data_ptr())
+    torch.cuda.synchronize()
+    f32 = np.float32
+    want = l1 * l1[:, 3:4] + l0 * (f32(1) - l0[:, 3:4])
+    got = out.cpu().numpy()
+    assert np.allclose(got, want, rtol=0, atol=2e-7)         # (the device may fuse the multiply-add of the blend)
+    q = np.clip(got * f32(255) + f32(0.5), 0, 255).astype(np.uint32)
+    want_pix = (q[:, 2] | (q[:, 1] << 8) | (q[:, 0] << 16) | np.uint32(0xFF000000)).astype(np.uint32)
+    assert np.array_equal(pix.cpu().numpy().view(np.uint32), want_pix)
+    # one layer only: the layer itself
+    rt.composite_layers(gpu, a.data_ptr(), None, n, out.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), l0)

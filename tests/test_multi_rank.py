@@ -85,6 +85,36 @@ def test_partition_is_exact_cover():
     assert len(idx) == first[2] + (W - (tx - 1) * TILE) * (H - (ty - 1) * TILE)
 
 
+def test_library_shard_plan_equals_the_python_module(rt):
+    """rt_shard_plan / rt_shard_ray_indices (what a C++ host calls) deal the squares, and list a rank's rays and the scatter
+    tables, exactly as raytrace_amd.tiles does: round-robin and by cost, image sizes the square does not divide included."""
+    from raytrace_amd.tiles import assign_tiles, rays_of_tiles, tile_costs_from_units, tile_grid
+    rng = np.random.default_rng(11)
+    for (w, h, tile) in ((600, 360, 64), (640, 360, 64), (328, 200, 32), (64, 64, 64)):
+        units = rng.integers(0, 300, ((h + 7) // 8, (w + 7) // 8)).astype(np.uint32)
+        tx, ty = tile_grid(w, h, tile)
+        for world in (1, 2, 3, 8):
+            for costs in (None, units):
+                plan = rt.ShardPlan(w, h, tile, world, costs)
+                want = assign_tiles(tx * ty, world, None if costs is None else tile_costs_from_units(costs, w, h, tile))
+                base = 0
+                ids, first = plan.scatter_tables()
+                at = 0
+                for r in range(world):
+                    assert np.array_equal(plan.tiles[r].astype(np.int64), want[r]), (w, h, world, r)
+                    idx, tf = rays_of_tiles(w, h, tile, want[r])
+                    assert np.array_equal(plan.ray_indices(r), idx.astype(np.uint32))
+                    assert int(plan.first_record[r]) == base and plan.records(r) == len(idx)
+                    assert np.array_equal(first[at:at + len(tf)], tf + np.uint32(base))
+                    base += len(idx)
+                    at += len(tf)
+                assert base == w * h and int(plan.first_record[world]) == w * h
+    # bad arguments are errors, not crashes
+    assert rt.lib.rt_shard_plan(0, 10, 8, 1, None, None, None, None) == -1
+    out = np.zeros(4, np.uint32)
+    assert rt.lib.rt_shard_ray_indices(64, 64, 32, rt._ptr(np.array([9], np.uint32)), 1, 0, rt._ptr(out), None) == -1
+
+
 def test_cost_balanced_assignment_evens_out_the_ranks(rt):
     """Dragon framed at 960x540 (a quarter-size stand-in for the 3840x2160 configuration: the same silhouette on
     the same 60 x 34 grid of squares): per-square cost from the host fetch counter; the modelled max / mean of
