@@ -81,14 +81,24 @@ def parse():
     ap.add_argument("--cpu-stride", type=int, default=4, help="sub-grid stride (both axes) of the CPU baseline sample")
     ap.add_argument("--tile", type=int, default=64, help="tiles4k: side of the squares dealt to the ranks (multiple of 8)")
     ap.add_argument("--assign", default="cost", choices=["cost", "roundrobin"], help="tiles4k: how squares are dealt to ranks")
-    ap.add_argument("--gather", default="hits8", choices=["hits8", "hits16", "bgra8"],
-                    help="tiles4k: what crosses the GPUs into rank 0's framebuffer: the 8-byte {id,t} of every pixel (default), its 16-byte "
-                         "{id,t,u,v} hit, or its shaded 8-bit BGRA pixel (the full trace step + rt_pack_bgra8)")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--gather", default="bgra8", choices=["bgra8", "id4", "hits8", "hits16"],
+                    help="tiles4k: what crosses the GPUs into rank 0's framebuffer: every pixel's shaded 8-bit BGRA value (the full trace "
+                         "step with the pixel packed in the kernel, the default), or its closest hit as a 4-byte {id}, 8-byte {id,t} or "
+                         "16-byte {id,t,u,v} record")
+    ap.add_argument("--pipeline", type=int, default=-1, choices=[-1, 0, 1, 2, 3, 4],
                     help="tiles4k: frames in flight, each on a stream of its own (trace, exchange and scatter of a frame on its stream, so "
-                         "the exchange of a frame runs beside the traces of the next ones); 0 = one frame at a time on the caller's stream")
-    ap.add_argument("--scene-per-stream", type=int, default=0,
+                         "the exchange of a frame runs beside the traces of the next ones); 0 = one frame at a time on the caller's stream; "
+                         "-1 (default) = a few pipelines are timed briefly at start-up and the best is kept")
+    ap.add_argument("--side-stream", type=int, default=1, choices=[0, 1],
+                    help="tiles4k with a fixed --pipeline: 0 = the scenes build their launch orders on the frame's stream (\"side_stream\" 0)")
+    ap.add_argument("--scene-per-stream", type=int, default=1,
                     help="tiles4k: 1 = every frame in flight has a scene object of its own (own launch-order tables and side stream)")
+    ap.add_argument("--redeal", type=int, default=0, metavar="K",
+                    help="tiles4k: deal the squares again every K frames inside the timed loop, from costs every rank measures on its own "
+                         "squares (0 = only the deal at start-up, made the same way; one re-deal is always timed on its own and reported)")
+    ap.add_argument("--root-head-start", type=float, default=-1.0,
+                    help="tiles4k: share of the whole frame's cost rank 0 counts as carrying before the squares are dealt (its gather "
+                         "and scatter); negative = measured at start-up (scatter of a whole frame / one-GPU frame time)")
     ap.add_argument("--image-hint", type=int, default=1, help="declare the ray array as a W-wide image (8x8 tiles per wave)")
     ap.add_argument("--raygen", default="table", choices=["table", "device"],
                     help="table: rays are a RayIntersection array resident in HBM (the reference's interface); device: "
@@ -316,31 +326,21 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
             sc.set_param(k, int(v))
         return sc
     scene = new_scene()
-    more_scenes = []
+    scene_sets, stream_sets = {}, {}      # per (frames in flight, side stream): the scene objects and streams of that pipeline, made once
     info = scene.info()
     box = bvh.root_box
     origin = rt.frame_camera(box, W, H)
     null_stream = torch.cuda.current_stream().cuda_stream
     extra = {}
-    # every rank measures the same per-tile costs with one untimed pass of its own (deterministic wave iteration counts), so
-    # all ranks derive the same plan without exchanging anything
-    units = scene.unit_costs_primary(W, H, origin)
     R = a.share_of if (a.share_of > 1 and world == 1) else world
-    plan = rt.ShardPlan(W, H, a.tile, R, units if a.assign == "cost" else None)
     me = rank if R == world else 0
+    stand_for = [rank] if R == world else list(range(R))     # the ranks whose measurements this process makes
     if R != world:
         extra["rehearsal"] = f"rank 0's share of {a.share_of} ranks on one GPU, no exchange; value counts only those rays"
     full_h = rt.primary_rays(W, H, origin)
-    rays_h = full_h[plan.ray_indices(me)]
-    n_local = len(rays_h)
-    rays_d = torch.from_numpy(rays_h).cuda()
+    full_d = torch.from_numpy(full_h).cuda()                 # the frame's ray table; a rank's rays are gathered from it on the device
     hint = a.tile if (a.image_hint and W % a.tile == 0) else 0
-    scene.set_param("image_width", hint)     # a rank's rays are its squares stacked: an image one square wide, so waves keep 8x8 blocks
     from raytrace_amd import tiles as tl
-    sq_costs = tl.tile_costs_from_units(units, W, H, a.tile)
-    extra["tile_assignment"] = {"squares": len(plan.tile_order), "side": a.tile, "by": a.assign, "planned_by": "rt_shard_plan",
-                                "modelled_max_over_mean_cost": round(tl.balance([t.astype(np.int64) for t in plan.tiles], sq_costs), 4),
-                                "round_robin_would_be": round(tl.balance(tl.assign_tiles(len(plan.tile_order), R, None), sq_costs), 4)}
     cam = np.eye(4, dtype=np.float32)
     comm = None
     if world > 1 and a.backend == "nccl":
@@ -350,14 +350,108 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         dist.broadcast(idt, 0)
         comm = rt.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local)
 
-    REC = {"hits16": 16, "hits8": 8, "bgra8": 4}
-    WHAT = {"hits16": "16 B {id,t,u,v}", "hits8": "8 B {id,t} (rt_pack_hits8)", "bgra8": "8-bit BGRA pixel (full trace step + rt_pack_bgra8)"}
+    def sum_over_ranks(values):
+        """In place, float64 host array: the sum over the job's ranks (RCCL through the library; gloo in the rehearsal)."""
+        if comm is not None:
+            comm.sum_f64(values)
+        elif dist:
+            dist.all_reduce(torch.from_numpy(values))
+        return values
 
-    def build(payload, frames_in_flight):
-        """Buffers and the step of the sharded frame for one kind of gathered record and one pipeline depth."""
+    def share_rays(plan, r):
+        idx = torch.from_numpy(plan.ray_indices(r).astype(np.int64)).cuda()
+        return full_d.index_select(0, idx)
+
+    def measured_square_costs(plan):
+        """Per-square traversal cost of the current frame, measured where the squares are traced: every rank runs the
+        instrumented launch over its OWN rays (its squares stacked, the image hint it traces them with), adds the work-unit
+        costs up per square (rt_shard_square_costs), and the arrays are summed over the ranks."""
+        sq = np.zeros(len(plan.tile_order), np.float64)
+        scene.set_param("image_width", hint)
+        for r in stand_for:
+            rays_r = share_rays(plan, r)
+            plan.square_costs_of_rank(r, scene.unit_costs(rays_r.data_ptr(), len(rays_r)), hint, sq)
+            del rays_r
+        return sum_over_ranks(sq)
+
+    REC = {"hits16": 16, "hits8": 8, "id4": 4, "bgra8": 4}
+    rec_default = REC[a.gather]
+
+    def one_gpu_call(sc, rays_ptr, n, out_ptr, payload, q):
+        if payload == "bgra8":   # the full trace step (identity camera), the pixel written as 8-bit BGRA by the kernel itself
+            sc.trace_pass_bgra8(rays_ptr, None, out_ptr, n, cam, 0, q)
+        else:                    # closest hits, only the record that crosses the GPUs
+            sc.intersect_compact(rays_ptr, n, out_ptr, REC[payload], q)
+
+    # What the gathering rank does besides tracing (the scatter of the whole frame), as a share of the time one GPU needs for
+    # the frame: its head start in the deal.  Measured on rank 0, handed to the others by a sum.
+    head = np.zeros(R, np.float64)
+    one_ms = None
+    if R > 1 and a.root_head_start < 0:
+        hs = np.zeros(1, np.float64)
+        if rank == 0:
+            rr = rt.ShardPlan(W, H, a.tile, R)
+            ids_h, first_h = rr.scatter_tables()
+            ids_t, first_t = torch.from_numpy(ids_h.astype(np.int32)).cuda(), torch.from_numpy(first_h.astype(np.int32)).cuda()
+            g = torch.zeros((W * H, rec_default // 4), dtype=torch.int32, device="cuda")
+            fb = torch.zeros_like(g)
+            whole = np.array([0, W * H], np.uint64)
+
+            def scatter_whole():
+                rt.gather_scatter(None, 0, 1, 0, local, g.data_ptr(), g.data_ptr(), whole, rec_default, ids_t.data_ptr(), first_t.data_ptr(),
+                                  len(ids_h), a.tile, W, H, fb.data_ptr(), null_stream)
+            probe = new_scene()      # a scene of its own: the job's scenes and their streams start untouched
+            probe.set_param("image_width", W)
+
+            def trace_whole():
+                one_gpu_call(probe, full_d.data_ptr(), W * H, g.data_ptr(), a.gather, null_stream)
+            t = []
+            for fn, warm in ((scatter_whole, 3), (trace_whole, 12)):
+                for _ in range(warm):
+                    fn()
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                for _ in range(20):
+                    fn()
+                torch.cuda.synchronize()
+                t.append((time.perf_counter() - c0) / 20 * 1e3)
+            one_ms = t[1]
+            hs[0] = t[0] / t[1]
+            extra["root_scatter_whole_frame_ms"] = round(t[0], 4)
+            probe.close()
+            del g, fb
+        head[0] = float(sum_over_ranks(hs)[0]) if R == world else float(hs[0])
+    elif R > 1:
+        head[0] = a.root_head_start
+    extra["root_head_start"] = round(float(head[0]), 4)
+
+    # The deal: start round-robin, measure, deal by cost.  The same two calls re-deal the squares while the job runs.
+    plan = rt.ShardPlan(W, H, a.tile, R)
+    sq_costs = measured_square_costs(plan)
+    if a.assign == "cost":
+        plan = rt.ShardPlan(W, H, a.tile, R, None, sq_costs, head)
+    extra["tile_assignment"] = {"squares": len(plan.tile_order), "side": a.tile, "by": a.assign, "planned_by": "rt_shard_square_costs + rt_shard_plan",
+                                "modelled_max_over_mean_cost": round(tl.balance([t.astype(np.int64) for t in plan.tiles[1:]] if R > 1 else
+                                                                                [t.astype(np.int64) for t in plan.tiles], sq_costs), 4),
+                                "root_share_of_cost": round(float(sq_costs[plan.tiles[0]].sum() / max(1.0, sq_costs.sum())), 4),
+                                "round_robin_would_be": round(tl.balance(tl.assign_tiles(len(plan.tile_order), R, None), sq_costs), 4)}
+    rays_d = share_rays(plan, me)
+    n_local = len(rays_d)
+    scene.set_param("image_width", hint)     # a rank's rays are its squares stacked: an image one square wide, so waves keep 8x8 blocks
+
+    WHAT = {"hits16": "16 B {id,t,u,v}", "hits8": "8 B {id,t}", "id4": "4 B {id}", "bgra8": "8-bit BGRA pixel (full trace step, rt_trace_pass_bgra8)"}
+
+    def build(payload, frames_in_flight, side=1):
+        """Buffers and the step of the sharded frame for one kind of gathered record and one pipeline: `frames_in_flight` frames,
+        each on a stream of its own with a scene object of its own; side = 0: the scenes build their launch orders on the frame's
+        stream instead of a side stream each.  Streams and scenes of a pipeline are made once and kept: a stream keeps the
+        hardware queue it was given, so a pipeline that was timed is the pipeline that runs."""
         rec_b = REC[payload]
         NB = max(1, frames_in_flight)
-        streams = [torch.cuda.Stream() for _ in range(NB)] if frames_in_flight >= 1 else None
+        key = (frames_in_flight, side)
+        if frames_in_flight >= 1 and key not in stream_sets:
+            stream_sets[key] = [torch.cuda.Stream() for _ in range(NB)]
+        streams = stream_sets[key] if frames_in_flight >= 1 else None
 
         def raw(b):
             return streams[b].cuda_stream if streams else null_stream
@@ -366,11 +460,13 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
             return torch.empty((nrec, rec_b // 4), dtype=torch.int32, device="cuda")
 
         scn = [scene] * NB
-        if a.scene_per_stream and NB > 1:
-            while len(more_scenes) < NB - 1:
-                more_scenes.append(new_scene())
-                more_scenes[-1].set_param("image_width", hint)
-            scn = [scene] + more_scenes[:NB - 1]
+        if frames_in_flight >= 1 and (a.scene_per_stream or side == 0):
+            if key not in scene_sets:
+                scene_sets[key] = [new_scene() for _ in range(NB if a.scene_per_stream else 1)]
+                for sc in scene_sets[key]:
+                    sc.set_param("image_width", hint)
+                    sc.set_param("side_stream", side)
+            scn = [scene_sets[key][b % len(scene_sets[key])] for b in range(NB)]
         root = me == 0
         if R == world:
             first_record = plan.first_record
@@ -387,22 +483,12 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         first_d = torch.from_numpy(first_h.astype(np.int32)).cuda() if root else None
         lo = int(first_record[me])
         mine = [g[lo:lo + n_local] for g in gather] if root else [records(n_local) for _ in range(NB)]   # root traces into its slice
-        h16 = [torch.empty((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(NB)] if payload == "hits8" else None
-        rgba = [torch.empty((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(NB)] if payload == "bgra8" else None
         host_in = [torch.empty((int(first_record[r + 1] - first_record[r]), rec_b // 4), dtype=torch.int32) for r in range(world)] \
             if (world > 1 and comm is None and root) else None
-        state = types.SimpleNamespace(frame=0, last=None)
+        state = types.SimpleNamespace(frame=0, last=None, fresh=True)
 
         def trace_into(b):
-            q = raw(b)
-            if payload == "bgra8":   # the full trace step (identity camera) writes the RGBA32F pixel; packed to 8-bit BGRA for the wire
-                scn[b].trace_pass(rays_d.data_ptr(), None, rgba[b].data_ptr(), n_local, cam, 0, q)
-                rt.pack_bgra8(local, rgba[b].data_ptr(), n_local, mine[b].data_ptr(), q)
-            elif payload == "hits8":
-                scn[b].intersect_async(rays_d.data_ptr(), n_local, None, h16[b].data_ptr(), q)
-                rt.pack_hits8(local, h16[b].data_ptr(), n_local, mine[b].data_ptr(), q)
-            else:
-                scn[b].intersect_async(rays_d.data_ptr(), n_local, None, mine[b].data_ptr(), q)
+            one_gpu_call(scn[b], rays_d.data_ptr(), n_local, mine[b].data_ptr(), payload, raw(b))
 
         def exchange(b):
             q = raw(b)
@@ -445,6 +531,7 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
                 for st in streams:
                     st.wait_stream(cur)
         return types.SimpleNamespace(payload=payload, rec_b=rec_b, NB=NB, nstreams=len(streams) if streams else 1, step=step, flush=flush, start=start,
+                                     frames_in_flight=frames_in_flight, side=side,
                                      trace_into=trace_into, exchange=exchange, fbs=fbs, state=state, first_record=first_record)
 
     def run(sh, steps, warm):
@@ -459,8 +546,63 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()) * 1e3 / max(1, steps)
 
-    sh = build(a.gather, a.pipeline)
-    ms_per_step = run(sh, a.steps, a.warmup)
+    def redeal():
+        """The squares dealt again from the costs of the frame as it is traced now (measured on every rank's own rays, summed
+        over the ranks): what follows a moving camera.  Everything in flight is finished first; buffers are rebuilt."""
+        nonlocal plan, rays_d, n_local, sh
+        sh.flush()
+        torch.cuda.synchronize()
+        before = np.empty(len(plan.tile_order), np.int32)
+        for r in range(R):
+            before[plan.tiles[r]] = r
+        sq = measured_square_costs(plan)
+        plan = rt.ShardPlan(W, H, a.tile, R, None, sq, head) if a.assign == "cost" else plan
+        after = np.empty(len(plan.tile_order), np.int32)
+        for r in range(R):
+            after[plan.tiles[r]] = r
+        rays_d = share_rays(plan, me)
+        n_local = len(rays_d)
+        sh = build(a.gather, sh.frames_in_flight, sh.side)
+        sh.start()
+        return int((before != after).sum())
+
+    def stepper():
+        if a.redeal > 0 and sh.state.frame > 0 and sh.state.frame % a.redeal == 0 and not sh.state.fresh:
+            redeal()
+        sh.state.fresh = False
+        sh.step()
+
+    if a.pipeline >= 0:
+        sh = build(a.gather, a.pipeline, a.side_stream)
+    else:
+        # Which pipeline: streams share the GPU's few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in the order they were
+        # first used, and a stream whose head waits -- a side stream for a launch's end, a frame stream for its records to arrive
+        # -- holds up every stream mapped to the same queue.  How that falls out depends on the process (its other streams, the
+        # communication library's), so a few pipelines are timed for a moment on every rank and the one with the best slowest
+        # rank is kept, streams, scenes and all.
+        cands = [(4, 1), (3, 1), (3, 0), (2, 0), (4, 0)]
+        tried = {}
+        for c in cands:
+            cand = build(a.gather, c[0], c[1])
+            tried[c] = (run(cand, 40, 24), cand)
+        best = min(cands, key=lambda c: tried[c][0])
+        sh = tried[best][1]
+        extra["pipelines_tried"] = [{"frames_in_flight": c[0], "side_stream": c[1], "ms_per_step": round(tried[c][0], 4)} for c in cands]
+        del tried, cand
+    if a.redeal > 0:
+        for _ in range(a.warmup):
+            sh.step()
+        sh.flush()
+        torch.cuda.synchronize()
+        sh.start()
+        w_all, _ = timed(dist, a.steps, stepper, lambda: sh.flush())
+        t_all = torch.tensor([w_all], dtype=torch.float64, device=red_dev)
+        if dist:
+            dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        ms_per_step = float(t_all.item()) * 1e3 / max(1, a.steps)
+        extra["squares_redealt_every_frames"] = a.redeal
+    else:
+        ms_per_step = run(sh, a.steps, a.warmup)
     # what the host spends enqueueing a step (nothing waited for): the floor of a step however fast the GPU is
     torch.cuda.synchronize()
     c0 = time.perf_counter()
@@ -491,31 +633,34 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
     extra["gathered_record"] = WHAT[a.gather]
     extra["frames_in_flight"] = sh.NB
     extra["streams"] = sh.nstreams
+    extra["launch_orders_built_on"] = "a side stream per scene" if sh.side else "the frame's own stream"
     extra["exchange"] = ("rt_gather_scatter over an RCCL communicator made by rt_comm_create" if comm is not None else
                          ("rt_gather_scatter, one rank" if world == 1 else "gloo through host memory (rehearsal) + rt_gather_scatter for the scatter"))
-    if a.pipeline >= 1:
+    if sh.frames_in_flight >= 1:
         ms_1 = run(solo, sub, 2)
         extra["same_steps_one_frame_at_a_time"] = {"ms_per_step": round(ms_1, 4), "value": round(n_total / (ms_1 * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
     del solo
+    # one re-deal, untimed: what it costs, and (same camera) that it deals the same squares to the same ranks
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    c0 = time.perf_counter()
+    moved = redeal()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    extra["redeal"] = {"ms": round((time.perf_counter() - c0) * 1e3, 2), "squares_that_changed_rank": moved,
+                       "what": "every rank measures its own squares (rt_scene_unit_costs + rt_shard_square_costs), the costs are summed over the "
+                               "ranks (rt_comm_sum_f64), rt_shard_plan deals again, ray tables and buffers are rebuilt"}
 
     if world > 1:
         # the whole frame on ONE GPU of this job (rank 0 alone, the others wait): the strong-scaling reference point
         if rank == 0:
-            full_d = torch.from_numpy(full_h).cuda()
-            one16 = torch.empty((W * H, 4), dtype=torch.float32, device="cuda")
             one_out = torch.empty((W * H, sh.rec_b // 4), dtype=torch.int32, device="cuda")
-            one_rgba = torch.empty((W * H, 4), dtype=torch.float32, device="cuda") if a.gather == "bgra8" else None
             scene.set_param("image_width", W)
 
             def one_gpu_frame():
-                if a.gather == "bgra8":
-                    scene.trace_pass(full_d.data_ptr(), None, one_rgba.data_ptr(), W * H, cam, 0, null_stream)
-                    rt.pack_bgra8(local, one_rgba.data_ptr(), W * H, one_out.data_ptr(), null_stream)
-                elif a.gather == "hits8":
-                    scene.intersect_async(full_d.data_ptr(), W * H, None, one16.data_ptr(), null_stream)
-                    rt.pack_hits8(local, one16.data_ptr(), W * H, one_out.data_ptr(), null_stream)
-                else:
-                    scene.intersect_async(full_d.data_ptr(), W * H, None, one_out.data_ptr(), null_stream)
+                one_gpu_call(scene, full_d.data_ptr(), W * H, one_out.data_ptr(), a.gather, null_stream)
             for _ in range(10):
                 one_gpu_frame()
             torch.cuda.synchronize()
@@ -536,11 +681,11 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         torch.cuda.synchronize()
         if rank == 0:
             extra["framebuffer_equals_one_gpu"] = bool(torch.equal(sh.state.last, one_out))
-            del full_d, one16, one_out, one_rgba
+            del one_out
         dist.barrier()
         # the same sharded frame with the 16-byte hit as the gathered record (twice the bytes on the links)
         if a.gather != "hits16":
-            alt = build("hits16", a.pipeline)
+            alt = build("hits16", sh.frames_in_flight, sh.side)
             ms_a = run(alt, sub, max(2, a.warmup // 4))
             extra["same_frame_gathered_as"] = {"record": WHAT["hits16"], "ms_per_step": round(ms_a, 4), "value": round(W * H / (ms_a * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
             del alt
@@ -584,7 +729,7 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
                                     "node_bytes": info["node4_bytes"], "tri_bytes": info["tri_bytes"],
                                     "hit_fraction": round(cnt["rays_hit"] / cnt["rays"], 4)}}
         cpu = cpu_bvh = None
-        if world == 1 and R == 1 and not a.no_cpu_baseline and a.gather != "bgra8":
+        if world == 1 and R == 1 and not a.no_cpu_baseline and a.gather in ("hits8", "hits16"):
             import oracle  # the CPU checker, used here only as the timed baseline
             for fb in sh.fbs:
                 fb.fill_(-1)            # wiped first: the check below must see THIS step's gather and scatter
@@ -633,8 +778,9 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         dist.barrier()
     if comm is not None:
         comm.close()
-    for sc in more_scenes:
-        sc.close()
+    for group in scene_sets.values():
+        for sc in group:
+            sc.close()
     scene.close()
     if dist:
         dist.destroy_process_group()
@@ -662,18 +808,17 @@ def main():
             dist.init_process_group("gloo")
     red_dev = "cuda" if a.backend == "nccl" else "cpu"   # where the scalar reductions below live
     workload = a.workload or ("dragon1080" if world == 1 else "tiles4k")
-    sharded = workload == "tiles4k"
     if workload == "mirror5":
         if world != 1:
             raise SystemExit("--workload mirror5 runs on one GPU")
         run_mirror5(a, local)
         return
-    if sharded:
+    if workload == "tiles4k":
         run_tiles4k(a, rank, world, local, dist, red_dev)
         return
 
     model, W, H = WORKLOADS[workload]
-    mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "reference" if workload == "mirror5" else "tolerant")
+    mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "tolerant")
     bvh = rt.BVH(mesh, a.bvh)
     width = 4 if a.width == 4 else 2
 
@@ -713,32 +858,10 @@ def main():
         frames, origins, tables = 1, [], [rays_d]
     else:
         origin = rt.frame_camera(box, W, H)
-        if sharded:
-            assert a.tile % 8 == 0
-            tx, ty = tl.tile_grid(W, H, a.tile)
-            # every rank measures the same per-square costs with one untimed pass of its own (deterministic wave
-            # iteration counts), so all ranks derive the same assignment without exchanging anything
-            costs = tl.tile_costs_from_units(scene.unit_costs_primary(W, H, origin), W, H, a.tile)
-            all_lists = tl.assign_tiles(tx * ty, world, costs if a.assign == "cost" else None)
-            if a.share_of > 1 and world == 1:
-                all_lists = [tl.assign_tiles(tx * ty, a.share_of, costs if a.assign == "cost" else None)[0]]
-                extra["rehearsal"] = f"rank 0's share of {a.share_of} ranks on one GPU, no exchange; value counts only those rays"
-            idx, _ = tl.rays_of_tiles(W, H, a.tile, all_lists[rank])
-            full = rt.primary_rays(W, H, origin)
-            rays_h = full[idx]
-            del full
-            extra["tile_assignment"] = {"squares": int(tx * ty), "side": a.tile, "by": a.assign,
-                                        "modelled_max_over_mean_cost": round(tl.balance(all_lists, costs), 4),
-                                        "round_robin_would_be": round(tl.balance(tl.assign_tiles(tx * ty, world, None), costs), 4)}
-            if a.image_hint and W % a.tile == 0:
-                # a rank's rays are its squares one after another, each row-major and a.tile pixels wide: to the library
-                # that is an image a.tile wide and (squares x rows) tall, so waves still take 8x8 pixel blocks
-                scene.set_param("image_width", a.tile)
-        else:
-            origin[0] += rank * 0.01 * float(box[1, 0] - box[0, 0])  # each rank renders its own frame
-            rays_h = rt.primary_rays(W, H, origin)
-            if a.image_hint:
-                scene.set_param("image_width", W)
+        origin[0] += rank * 0.01 * float(box[1, 0] - box[0, 0])  # each rank renders its own frame
+        rays_h = rt.primary_rays(W, H, origin)
+        if a.image_hint:
+            scene.set_param("image_width", W)
         n_local = len(rays_h)
         rays_d = torch.from_numpy(rays_h).cuda()
         # A render loop never traces the same rays twice: frame k of the timed loop looks from origin_k, a camera
@@ -752,140 +875,15 @@ def main():
             if k > 0 and a.raygen == "table":
                 tables.append(torch.from_numpy(rt.primary_rays(W, H, o)).cuda())
     step_no = [0]
-    full_out = (a.out == "full" or workload == "mirror5") and not sharded
+    full_out = a.out == "full"
     out_b = 64 if full_out else 16
     hits_d = torch.empty((n_local, 16 if full_out else 4), dtype=torch.float32, device="cuda")
-
-    passes = 5 if workload == "mirror5" else 1
-    if workload == "mirror5":
-        pong = torch.empty((n_local, 16), dtype=torch.float32, device="cuda")
-        rgba_d = torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
-        cam = np.eye(4, dtype=np.float32)
-
-    # ---- sharded image: gather buffers, square lists and the exchange --------------------------------------
-    cam = np.eye(4, dtype=np.float32)
-
-    def build_sharded(pix):
-        """Buffers and closures of the sharded frame for one kind of gathered record: 16-byte hits (pix False) or 8-bit pixels."""
-        rec_b = 4 if pix else 16
-
-        def records(nrec):
-            return torch.empty((nrec, 1), dtype=torch.int32, device="cuda") if pix else torch.empty((nrec, 4), dtype=torch.float32, device="cuda")
-
-        counts = [len(tl.rays_of_tiles(W, H, a.tile, l)[0]) for l in all_lists]
-        bases = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        NB = 2     # frames in flight: the exchange of one runs beside the trace of the next
-        # --pipeline 2: the two frames in flight also live on two streams (trace, exchange and scatter of frame buffer b on
-        # stream b), so the tail of one rank-sized launch -- a handful of long waves on an otherwise idle chip, most of the
-        # launch once a frame is cut into N parts -- overlaps the head of the next frame's.
-        two = {"on": a.pipeline == 2}
-        tstreams = [torch.cuda.Stream(), torch.cuda.Stream()] if a.pipeline == 2 else None
-
-        def on_stream(b):
-            return torch.cuda.stream(tstreams[b]) if two["on"] else contextlib.nullcontext()
-
-        def raw_stream(b):
-            return tstreams[b].cuda_stream if two["on"] else stream
-
-        fb_last = [None]
-        if rank == 0:
-            gather_d = [records(W * H) for _ in range(NB)]       # squares of rank 0, 1, ... back to back
-            fbs = [records(W * H) for _ in range(NB if a.pipeline == 2 else 1)]   # the row-major framebuffer(s), one per stream
-            fb_last[0] = fbs[0]
-            ids_h = np.concatenate(all_lists).astype(np.int32)
-            first_h = np.concatenate([tl.rays_of_tiles(W, H, a.tile, l)[1].astype(np.int64) + bases[r]
-                                      for r, l in enumerate(all_lists)]).astype(np.int32)
-            ids_d, first_d = torch.from_numpy(ids_h).cuda(), torch.from_numpy(first_h).cuda()
-            mine = [g[:counts[0]] for g in gather_d]             # rank 0 traces straight into its slice of the gather buffer
-            slices = [[g[bases[r]:bases[r + 1]] for r in range(world)] for g in gather_d]
-        else:
-            mine = [records(n_local) for _ in range(NB)]
-            fbs = []
-        if pix:
-            rgba_ds = [torch.empty((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(NB)]
-        pending = [None] * NB
-
-        def trace_into(b):
-            q = raw_stream(b)
-            if pix:   # the full trace step (identity camera) writes the RGBA32F pixel; packed to 8-bit BGRA for the wire
-                scene.trace_pass(rays_d.data_ptr(), None, rgba_ds[b].data_ptr(), n_local, cam, 0, q)
-                rt.pack_bgra8(local, rgba_ds[b].data_ptr(), n_local, mine[b].data_ptr(), q)
-            else:
-                scene.intersect_async(rays_d.data_ptr(), n_local, None, mine[b].data_ptr(), q)
-
-        def start_exchange(b):
-            """Every other rank's records of frame buffer b to rank 0 (point-to-point, grouped: rank 0 receives on its seven
-            xGMI links at once, no ring).  Returns the handles still to be waited for."""
-            if world == 1:
-                return []
-            with on_stream(b):   # the collective orders itself behind what the CURRENT stream holds: frame buffer b's trace
-                if rank == 0:
-                    ops = [dist.P2POp(dist.irecv, slices[b][r], r) for r in range(1, world)]
-                else:
-                    ops = [dist.P2POp(dist.isend, mine[b], 0)]
-                if a.backend == "nccl":
-                    return dist.batch_isend_irecv(ops)
-                for q in [op.op(op.tensor, op.peer) for op in ops]:
-                    q.wait()
-            return []
-
-        def finish_exchange(b):
-            """Waits (on the stream, not the host) for frame buffer b's records, then scatters them into the framebuffer."""
-            with on_stream(b):
-                for q in pending[b] or []:
-                    q.wait()
-            pending[b] = None
-            if rank == 0:
-                fb = fbs[b if two["on"] else 0]
-                rt.scatter_tiles(local, gather_d[b].data_ptr(), W * H, ids_d.data_ptr(), first_d.data_ptr(), len(ids_h), a.tile, W, H, rec_b,
-                                 fb.data_ptr(), raw_stream(b))
-                fb_last[0] = fb
-
-        def exchange():
-            pending[0] = start_exchange(0)
-            finish_exchange(0)
-
-        frame_no = [0]
-
-        def step_sharded():
-            b = frame_no[0] % NB
-            frame_no[0] += 1
-            trace_into(b)
-            if a.pipeline:
-                if pending[1 - b] is not None:
-                    finish_exchange(1 - b)       # the frame before: its records arrived while this one was traced
-                pending[b] = start_exchange(b)
-            else:
-                pending[b] = start_exchange(b)
-                finish_exchange(b)
-
-        def flush():
-            for b in range(NB):
-                if pending[b] is not None:
-                    finish_exchange(b)
-        return types.SimpleNamespace(pix=pix, rec_b=rec_b, records=records, counts=counts, two=two, NB=NB, mine=mine,
-                                     fbs=fbs, fb_last=fb_last, trace_into=trace_into, exchange=exchange, step=step_sharded, flush=flush)
-
-    if sharded:
-        sh = build_sharded(a.gather == "bgra8")
-        pix, rec_b, records, counts, two, NB = sh.pix, sh.rec_b, sh.records, sh.counts, sh.two, sh.NB
-        fbs, fb_last, trace_into, exchange, step_sharded, flush = sh.fbs, sh.fb_last, sh.trace_into, sh.exchange, sh.step, sh.flush
-        hits_d = sh.mine[0]
 
     def step():
         k = step_no[0] % frames
         step_no[0] += 1
         rays_k = tables[k] if k < len(tables) else rays_d
-        if workload == "mirror5":
-            # pass 0 reads the primary table; passes 1..4 reflect the previous pass's records (ping-pong)
-            scene.trace_pass(rays_d.data_ptr(), hits_d.data_ptr(), rgba_d.data_ptr(), n_local, cam, 0, stream)
-            src, dst = hits_d, pong
-            for _ in range(4):
-                scene.trace_pass(src.data_ptr(), dst.data_ptr(), rgba_d.data_ptr(), n_local, cam, 1, stream)
-                src, dst = dst, src
-        elif sharded:
-            step_sharded()
-        elif a.raygen == "device" and W:
+        if a.raygen == "device" and W:
             scene.trace_primary(W, H, origins[k], hits_d.data_ptr() if full_out else None,
                                 None if full_out else hits_d.data_ptr(), stream)
         elif full_out:
@@ -895,10 +893,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    if sharded:
-        flush()
-    wall, dev_ms = timed(dist, a.steps, step, flush if sharded else None)
-    dev_ms /= passes
+    wall, dev_ms = timed(dist, a.steps, step)
     if dist:
         tt = torch.tensor([wall], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -908,160 +903,30 @@ def main():
         n_total = int(nn.item())
     else:
         n_total = n_local
-    n_total *= passes
     ms_per_step = wall * 1e3 / max(1, a.steps)
     mrays = n_total / (ms_per_step * 1e-3) / 1e6
 
-    if sharded:
-        # the parts of the step on their own: trace only (slowest rank), exchange only
-        sub = max(5, a.steps // 4)
-        w_tr, _ = timed(dist, sub, lambda: trace_into(0))
-        w_ex, _ = timed(dist, sub, exchange)
-        parts = torch.tensor([w_tr / sub * 1e3, w_ex / sub * 1e3], dtype=torch.float64, device=red_dev)
-        if dist:
-            dist.all_reduce(parts, op=dist.ReduceOp.MAX)
-        extra["trace_only_ms"] = round(float(parts[0]), 4)
-        extra["gather_and_scatter_ms"] = round(float(parts[1]), 4)
-        extra["gather_bytes_into_rank0"] = int((W * H - counts[0]) * rec_b)
-        extra["gathered_record"] = "8-bit BGRA pixel (full trace step + rt_pack_bgra8)" if pix else "16 B {id,t,u,v}"
-        extra["frames_in_flight"] = NB if a.pipeline else 1
-        extra["streams"] = 2 if a.pipeline == 2 else 1
-        if a.pipeline == 2:
-            # the same pipelined steps with both frames in flight on ONE stream: every launch waits for the one before it
-            two["on"] = False
-            w_1, _ = timed(dist, sub, step, flush)
-            two["on"] = True
-            t1 = torch.tensor([w_1], dtype=torch.float64, device=red_dev)
-            if dist:
-                dist.all_reduce(t1, op=dist.ReduceOp.MAX)
-            ms_1 = float(t1.item()) * 1e3 / sub
-            extra["same_steps_on_one_stream"] = {"ms_per_step": round(ms_1, 4), "value": round(n_total / (ms_1 * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
-        if world > 1:
-            # the whole frame on ONE GPU of this job (rank 0 alone, the others wait): the strong-scaling reference point
-            if rank == 0:
-                full_d = torch.from_numpy(rt.primary_rays(W, H, origin)).cuda()
-                one_out = records(W * H)
-                one_rgba = torch.empty((W * H, 4), dtype=torch.float32, device="cuda") if pix else None
-                scene.set_param("image_width", W)
-
-                def one_gpu_frame():
-                    if pix:
-                        scene.trace_pass(full_d.data_ptr(), None, one_rgba.data_ptr(), W * H, cam, 0, stream)
-                        rt.pack_bgra8(local, one_rgba.data_ptr(), W * H, one_out.data_ptr(), stream)
-                    else:
-                        scene.intersect_async(full_d.data_ptr(), W * H, None, one_out.data_ptr(), stream)
-                for _ in range(5):
-                    one_gpu_frame()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(sub):
-                    one_gpu_frame()
-                torch.cuda.synchronize()
-                one_ms = (time.perf_counter() - t0) / sub * 1e3
-                extra["one_gpu_same_frame"] = {"ms_per_step": round(one_ms, 4), "value": round(W * H / (one_ms * 1e-3) / 1e6, 1),
-                                               "unit": "Mrays/s", "speedup_of_this_job": round(one_ms / ms_per_step, 3)}
-                # the gathered framebuffer must be the single-GPU framebuffer, byte for byte
-                scene.set_param("image_width", a.tile if (a.image_hint and W % a.tile == 0) else 0)
-                for fb in fbs:
-                    fb.fill_(-1)                 # every frame of the loop is the same image: only a wiped framebuffer proves this step's scatter
-                torch.cuda.synchronize()
-                step()
-                flush()
-                torch.cuda.synchronize()
-                extra["framebuffer_equals_one_gpu"] = bool(torch.equal(fb_last[0].view(torch.int32), one_out.view(torch.int32)))
-                del full_d, one_out, one_rgba
-            else:
-                step()
-                flush()
-            dist.barrier()
-            # the same sharded frame with the other kind of gathered record (a quarter, or four times, the bytes on the links)
-            alt = build_sharded(not pix)
-            for _ in range(max(2, a.warmup // 4)):
-                alt.step()
-            alt.flush()
-            w_a, _ = timed(dist, sub, alt.step, alt.flush)
-            ta = torch.tensor([w_a], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
-            ms_a = float(ta.item()) * 1e3 / sub
-            extra["same_frame_gathered_as"] = {"record": "16 B {id,t,u,v}" if pix else "8-bit BGRA pixel (full trace step + rt_pack_bgra8)",
-                                               "gather_bytes_into_rank0": int((W * H - alt.counts[0]) * alt.rec_b),
-                                               "ms_per_step": round(ms_a, 4), "value": round(W * H / (ms_a * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
-            del alt
-            # weak scaling beside it: every rank traces its own 1920x1080 dragon frame (64-byte records), no exchange
-            Wf, Hf = 1920, 1080
-            of = rt.frame_camera(box, Wf, Hf)
-            of[0] += rank * 0.01 * float(box[1, 0] - box[0, 0])
-            rays_f = torch.from_numpy(rt.primary_rays(Wf, Hf, of)).cuda()
-            hits_f = torch.empty((Wf * Hf, 16), dtype=torch.float32, device="cuda")
-            scene.set_param("image_width", Wf)
-
-            def step_f():
-                scene.intersect_async(rays_f.data_ptr(), Wf * Hf, hits_f.data_ptr(), None, stream)
-            for _ in range(a.warmup):
-                step_f()
-            w_f, _ = timed(dist, a.steps, step_f)
-            tf = torch.tensor([w_f], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
-            ms_f = float(tf.item()) * 1e3 / max(1, a.steps)
-            extra["frame_parallel_weak_scaling"] = {"workload": "dragon.obj 1920x1080 primary rays, one frame per rank, no exchange",
-                                                    "ms_per_step": round(ms_f, 4), "value": round(world * Wf * Hf / (ms_f * 1e-3) / 1e6, 1),
-                                                    "unit": "Mrays/s", "scaling": "weak"}
-            scene.set_param("image_width", a.tile if (a.image_hint and W % a.tile == 0) else 0)
-            del rays_f, hits_f
-
     if rank == 0:
         # ---- algorithmic bytes per ray: records the traversal fetches, counted exactly by the instrumented kernel ----
-        if workload == "mirror5":
-            scene.set_param("feedback", 0)   # the counting launch below is a primary pass only
         n_count = min(n_local, 1 << 24)
         cnt = scene.count_fetches_device(rays_d.data_ptr(), n_count)
         for more_rays in tables[1:]:   # records fetched: the mean over the frames the loop cycles through
             more = scene.count_fetches_device(more_rays.data_ptr(), n_count)
             cnt = {key: (max(cnt[key], more[key]) if key == "max_stack" else cnt[key] + more[key]) for key in cnt}
-        per_pass = None
-        if workload == "mirror5":
-            # The reflection passes trace rays the kernel derives from the records of the pass before
-            # (tracekernel.ck:227-233: reflect about the stored normal, step off the surface; a record that missed stays
-            # terminated).  The same rays are rebuilt here from each pass's input records and counted like any other rays.
-            per_pass = [{"pass": 0, "rays_traced": cnt["rays"], "node_records": cnt["nodes"], "tri_records": cnt["tris"]}]
-            scene.trace_pass(rays_d.data_ptr(), hits_d.data_ptr(), rgba_d.data_ptr(), n_local, cam, 0, stream)
-            torch.cuda.synchronize()
-            src, dst = hits_d, pong
-            for k in range(1, 5):
-                live = src[:, 14].view(torch.int32) != -1
-                d4, n4 = src[:, 4:8], src[:, 8:12]
-                s2 = 2.0 * (d4[:, 0] * n4[:, 0] + d4[:, 1] * n4[:, 1] + d4[:, 2] * n4[:, 2] + d4[:, 3] * n4[:, 3])
-                tab = torch.zeros_like(src)
-                tab[:, 0:3] = src[:, 0:3] + n4[:, 0:3] * 0.00001
-                tab[:, 3] = 1.0
-                tab[:, 4:7] = d4[:, 0:3] - s2[:, None] * n4[:, 0:3]
-                tab = tab[live].contiguous()
-                c = scene.count_fetches_device(tab.data_ptr(), len(tab)) if len(tab) else {"rays": 0, "nodes": 0, "tris": 0, "rays_hit": 0, "max_stack": 0, "leaves": 0}
-                per_pass.append({"pass": k, "rays_traced": c["rays"], "node_records": c["nodes"], "tri_records": c["tris"]})
-                cnt = {key: (max(cnt[key], c[key]) if key == "max_stack" else cnt[key] + c[key]) for key in cnt}
-                scene.trace_pass(src.data_ptr(), dst.data_ptr(), rgba_d.data_ptr(), n_local, cam, 1, stream)
-                torch.cuda.synchronize()
-                src, dst = dst, src
-                del tab
-            cnt["rays"] = 5 * n_local      # per ray RECORD of the five passes, terminated ones included (they fetch nothing)
         stride = max(1, len(rays_h) // 8192)
         cnt_cpu = scene.count_fetches(rays_h, stride)
         node_b = info["node4_bytes"] if width == 4 else info["node2_bytes"]
         n_node, n_tri = cnt["nodes"] / cnt["rays"], cnt["tris"] / cnt["rays"]
-        in_b = 0 if (a.raygen == "device" and W and workload not in ("tiles4k", "mirror5")) else 64
-        stream_b = in_b + out_b + (16 if workload == "mirror5" else 0)       # compulsory HBM bytes per ray
+        in_b = 0 if (a.raygen == "device" and W) else 64
+        stream_b = in_b + out_b       # compulsory HBM bytes per ray
         trav_b = n_node * node_b + n_tri * info["tri_bytes"]
-        if sharded:
-            dev_ms = extra["trace_only_ms"]      # the roofline figures are the trace kernel's, not the exchange's
-            if pix:
-                out_b = 16                       # the RGBA32F pixel the trace step writes (packed to 4 bytes by a second kernel)
         secs = dev_ms * 1e-3
         key = f"{workload}/{a.bvh}/w{width}/out{out_b}/{a.raygen}" + ("/refill" if refill_on else "")
         pmc_table, pmc_src = newest_profile_table("pmc_table.json")
         pmc = pmc_table.get(key) if world == 1 else None
         peaks, _ = newest_profile_table("l2_gather_peak.json")
         res = {"hbm": {"achieved": round(stream_b * n_local / secs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "what": f"compulsory streams: {in_b} B ray in + {out_b} B hit out" + (" + 16 B pixel" if workload == "mirror5" else "")}}
+                       "what": f"compulsory streams: {in_b} B ray in + {out_b} B hit out"}}
         res["hbm"]["frac"] = round(res["hbm"]["achieved"] / HBM_PEAK_GBS, 4)
         traffic = None
         if pmc:
@@ -1099,7 +964,6 @@ def main():
                             "tri_records_per_ray_cpu_sample": round(cnt_cpu["tris"] / max(1, cnt_cpu["rays"]), 3),
                             "traversal_GBs": round(trav_b * n_local / secs / 1e9, 1),
                             "hit_fraction": round(cnt["rays_hit"] / cnt["rays"], 4), "deepest_stack": cnt["max_stack"],
-                            "per_pass": per_pass,
                             "valu_lane_ops_per_ray": round(ops, 1),
                             "valu_lane_ops_frac_of_peak": round(ops * n_local / secs / (SIMDS * 32 * CLOCK_HZ), 4)},
         }
@@ -1125,7 +989,7 @@ def main():
 
         # the same frames with the rays generated in the kernel (rt_trace_primary: no 64-byte ray record is read)
         in_kernel = None
-        if world == 1 and W and not sharded and workload in ("dragon1080", "bunny1080", "dragon4k") and a.raygen == "table" and not a.no_compare:
+        if world == 1 and W and workload in ("dragon1080", "bunny1080", "dragon4k") and a.raygen == "table" and not a.no_compare:
             k_no = [0]
 
             def step_g():
@@ -1143,7 +1007,7 @@ def main():
         # one launch overlaps the head of the next.  Reported beside `value`, never as it: launches overlap, so there is no
         # per-launch duration to hold against a profile.
         overlapped = None
-        if world == 1 and W and not sharded and workload != "mirror5" and a.raygen == "table" and not a.no_compare:
+        if world == 1 and W and a.raygen == "table" and not a.no_compare:
             s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
             hits2 = [hits_d, torch.empty_like(hits_d)]
             k_no = [0]
@@ -1164,7 +1028,7 @@ def main():
 
         # the drop-in call with HOST buffers (pageable memory both ways): PCIe-inclusive, reported beside `value`, never as it
         host_call = None
-        if world == 1 and W and not sharded and workload != "mirror5" and full_out and not a.no_compare:
+        if world == 1 and W and full_out and not a.no_compare:
             hits_h = np.zeros_like(rays_h)
             for _ in range(2):
                 rt._check(rt.lib.ray_scene_intersection(rt._ptr(rays_h), n_local, scene._h, rt._ptr(hits_h)))
@@ -1178,17 +1042,10 @@ def main():
             del hits_h
 
         step_no[0] = 0
-        if not sharded:
-            step()                      # leaves frame 0's hits in hits_d for the spot check below
-        elif world == 1:
-            for fb in fbs:
-                fb.fill_(-1)            # wiped first: the spot check below must see THIS step's gather and scatter
-            torch.cuda.synchronize()
-            step()
-            flush()
+        step()                      # leaves frame 0's hits in hits_d for the spot check below
         torch.cuda.synchronize()
         cpu = None
-        if world == 1 and not a.no_cpu_baseline and workload != "mirror5":
+        if world == 1 and not a.no_cpu_baseline:
             import oracle  # the CPU checker, used here only as the timed baseline
             if workload == "ao":
                 every = max(1, len(rays_h) // 16384)
@@ -1198,24 +1055,13 @@ def main():
                 s = a.cpu_stride
                 sel = (np.arange(0, H, s)[:, None] * W + np.arange(0, W, s)[None, :]).reshape(-1)
                 what = f"stride-{s} sub-grid of the {W}x{H} ray set ({len(sel)} rays x {len(mesh.faces)} triangles, brute force)"
-            sample = rays_h[sel] if not sharded else rt.primary_rays(W, H, origin)[sel]
+            sample = rays_h[sel]
             threads = oracle.default_threads()
             c0 = time.perf_counter()
             oid, ot, _, _ = oracle.closest_hit(mesh.verts, mesh.faces, sample, threads=threads)
             cdt = time.perf_counter() - c0
             # parity spot-check of the same sample against the GPU result of the last step
-            if sharded and pix:
-                # the gathered framebuffer holds pixels, not hits: the sample is traced here once more for the check (the
-                # framebuffer itself is compared with the one-GPU frame byte for byte above)
-                sample_d = torch.from_numpy(np.ascontiguousarray(sample)).cuda()
-                src = torch.empty((len(sel), 4), dtype=torch.float32, device="cuda")
-                scene.set_param("image_width", 0)
-                scene.intersect_async(sample_d.data_ptr(), len(sel), None, src.data_ptr(), stream)
-                torch.cuda.synchronize()
-                got = src.cpu().numpy()
-            else:
-                src = fb_last[0] if sharded else hits_d
-                got = src[torch.from_numpy(sel).cuda()].cpu().numpy()
+            got = hits_d[torch.from_numpy(sel).cuda()].cpu().numpy()
             gid = got[:, 14 if full_out else 0].view(np.uint32)
             gt = got[:, 15 if full_out else 1]
             hit = oid != rt.MISS_ID
@@ -1226,21 +1072,17 @@ def main():
         # The accelerated CPU figure: the oracle's walk of the same CentroidBVH tree over EVERY ray of the step (the first 4 Mi of the
         # AO set), and with it a comparison of every hit of the last step with the CPU's.
         cpu_bvh = None
-        if world == 1 and not a.no_cpu_baseline and workload != "mirror5":
+        if world == 1 and not a.no_cpu_baseline:
             import oracle
-            all_rays = rays_h if not sharded else rt.primary_rays(W, H, origin)
+            all_rays = rays_h
             threads = oracle.default_threads()
             c0 = time.perf_counter()
             oid, ot, _, _ = oracle.closest_hit_bvh(mesh.verts, mesh.faces, bvh.nodes, all_rays, threads=threads)
             cdt = time.perf_counter() - c0
             hit = oid != rt.MISS_ID
-            if sharded and pix:      # the framebuffer holds pixels: nothing to hold against the CPU's hits
-                gid, gt = oid, ot
-            else:
-                src = fb_last[0] if sharded else hits_d
-                got = src[:len(all_rays)].cpu().numpy()
-                gid = got[:, 14 if full_out else 0].view(np.uint32)
-                gt = got[:, 15 if full_out else 1]
+            got = hits_d[:len(all_rays)].cpu().numpy()
+            gid = got[:, 14 if full_out else 0].view(np.uint32)
+            gt = got[:, 15 if full_out else 1]
             cpu_bvh = {"value": round(len(all_rays) / cdt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
                        "sample": f"all {len(all_rays)} rays" + (f" of the first slice of the {n_local}" if len(all_rays) != n_local else "") +
                                  ", closest hit through the same CentroidBVH tree (oracle tree walk)",
@@ -1248,32 +1090,27 @@ def main():
                        "t_bit_mismatches_vs_gpu": int((gt[hit].view(np.uint32) != ot[hit].view(np.uint32)).sum())}
             del all_rays
 
-        if workload == "mirror5":
-            what = f"{model} {W}x{H} primary pass + 4 reflection passes (full trace kernel)"
-        elif sharded:
-            what = f"{model} {W}x{H} primary rays, image tiles sharded over {world} GPU(s), framebuffer gathered to rank 0"
-        elif W:
+        if W:
             what = f"{model} {W}x{H} primary rays"
         else:
             what = f"{model} {n_local} AO rays per GPU"
         line = {
             "metric": "closest-hit Mrays/s", "value": round(mrays, 1), "unit": "Mrays/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": what, "name": workload, "rays_per_gpu": n_local, "rays_total": n_total, "triangles": len(mesh.faces),
-                       "loader": "reference" if workload == "mirror5" else "tolerant",
+                       "loader": "tolerant",
                        "bvh": {"fixed": "core/CentroidBVH build, centroid index repaired", "reference": "core/CentroidBVH build as written",
                                "sah": "library surface-area build"}[a.bvh],
                        "bvh_width": width, "nodes": info["nodes4" if width == 4 else "nodes2"],
-                       "hit_record": "64B RayIntersection" if out_b == 64 else ("16B RGBA32F pixel -> 4B BGRA" if (sharded and pix) else "16B {id,t,u,v}"),
+                       "hit_record": "64B RayIntersection" if out_b == 64 else "16B {id,t,u,v}",
                        "frames": frames,
                        "rays": "RayIntersection table resident in HBM" if in_b else "generated in the kernel (rt_trace_primary)",
                        "dispatch_order": ("a fixed grid of waves streams through the rays in index order, lanes take new rays as they finish (refill)" if refill_on
                                           else "costliest work unit first, from the costs a launch 2 to 10 launches earlier measured (re-sorted every 8th launch)"
                                           if a.feedback else "image centre first"),
-                       "parallelism": f"{world} x one process per GPU, " + ("cost-balanced image squares + RCCL gather (beside the next frame's trace) + device scatter"
-                                                                            if sharded else "frame-parallel")},
+                       "parallelism": f"{world} x one process per GPU, frame-parallel"},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_bvh": cpu_bvh, "same_launch_on_sah_tree": other, "rays_generated_in_kernel": in_kernel, "two_frames_in_flight": overlapped,
             "host_pointer_call": host_call,
         }

@@ -182,6 +182,13 @@ int ray_scene_intersection(const void *rays, size_t n, const rt_scene *scene, vo
 int rt_intersect_async(const rt_scene *scene, const void *rays_dev, size_t n, void *hits_dev, void *hits16_dev,
                        void *stream);
 
+/* rt_intersect_async with only a compact record per ray, of a chosen size: record_bytes 16 = {triangle_id, t, u, v},
+ * 8 = {triangle_id, t}, 4 = {triangle_id}; out_dev holds n of them.  The smaller records are what a frame of hits costs
+ * on the links between GPUs (rt_gather_scatter); the values are the same bits as the 16-byte record's.  No counterpart
+ * in the reference, whose kernel always writes the whole RayIntersection (render_client/tracekernel.ck:373-399). */
+int rt_intersect_compact(const rt_scene *scene, const void *rays_dev, size_t n, void *out_dev, size_t record_bytes,
+                         void *stream);
+
 /* rt_intersect_async for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  It computes the same
  * records as rt_intersect_async and always runs the cost-feedback schedule, but keeps the schedule's tables
@@ -214,6 +221,13 @@ int rt_trace_primary(const rt_scene *scene, int width, int height, const float o
  * `direction` unwritten, it sends those rays straight back where they came from. */
 int rt_trace_pass(const rt_scene *scene, const void *rays_in_dev, void *rays_out_dev, float *rgba_dev, size_t n,
                   const float cam[16], unsigned trace_operation, void *stream);
+
+/* rt_trace_pass with the pixel written as 8-bit BGRA (4 bytes, the byte order of rt_pack_bgra8 and of the reference's
+ * bitmap writer, cpu_raycast/bmp.c:49-53) instead of RGBA32F: the frame leaves the kernel in the form a framebuffer or
+ * the links between GPUs carry, without a packing pass.  bgra_dev holds n pixels; same bits as rt_pack_bgra8 of
+ * rt_trace_pass's pixels. */
+int rt_trace_pass_bgra8(const rt_scene *scene, const void *rays_in_dev, void *rays_out_dev, void *bgra_dev, size_t n,
+                        const float cam[16], unsigned trace_operation, void *stream);
 
 /* Mean records fetched per ray by the traversal, counted on the host over rays
  * 0, stride, 2*stride, ... : counts[0..5] = {node records, triangle records, non-empty
@@ -283,16 +297,27 @@ int rt_composite_layers(int device, const float *layer0_rgba_dev, const float *l
  * render_client/img_main.cpp:464-478.  Here the image is cut into tile x tile squares (edge squares smaller, numbered
  * row-major), every rank traces the squares dealt to it and the records are gathered into one rank's framebuffer.
  *
- * rt_shard_plan deals the squares to `nranks` ranks.  unit_costs (nullable) is the per-8x8-tile cost table of
- * rt_scene_unit_costs / _primary for this image ((ceil(height/8) x ceil(width/8)), row-major; tile must then be a
- * multiple of 8): squares go costliest first to the rank with the least cost so far, so the ranks finish together
- * whatever the silhouette looks like; the table is deterministic, so every rank derives the same plan without talking.
- * Without it the squares are dealt round-robin.  Re-planning from fresh costs every few frames follows a moving camera.
+ * rt_shard_plan deals the squares to `nranks` ranks.  Costs, at most one of: unit_costs = the per-8x8-tile cost table of
+ * rt_scene_unit_costs_primary for this image ((ceil(height/8) x ceil(width/8)), row-major; tile must then be a multiple of
+ * 8); square_costs = one cost per square (tiles_x * tiles_y, row-major), e.g. what rt_shard_square_costs summed from every
+ * rank's own last launch.  Squares go costliest first to the rank with the least cost so far, so the ranks finish together
+ * whatever the silhouette looks like; the tables are deterministic, so every rank derives the same plan from the same
+ * numbers.  With neither the squares are dealt round-robin.  rank_head_start (nullable, nranks values >= 0): the share of
+ * the WHOLE frame's cost a rank counts as carrying before the deal -- for the gathering rank, the time of its gather and
+ * scatter over the time one GPU needs for the frame -- so that it is dealt that much less.
  * Outputs: tile_order[tiles_x * tiles_y] = the squares rank after rank, each rank's in the order dealt (costliest first);
  * rank_first_tile[nranks + 1] = where each rank's squares start in tile_order; rank_first_record[nranks + 1] = where each
  * rank's records (pixels, square after square, row-major inside a square) start in the gather buffer. */
-int rt_shard_plan(int width, int height, int tile, int nranks, const uint32_t *unit_costs, uint32_t *tile_order,
-                  uint64_t *rank_first_tile, uint64_t *rank_first_record);
+int rt_shard_plan(int width, int height, int tile, int nranks, const uint32_t *unit_costs, const double *square_costs,
+                  const double *rank_head_start, uint32_t *tile_order, uint64_t *rank_first_tile, uint64_t *rank_first_record);
+/* Re-dealing while the job runs (a camera that moves): every rank measures the work-unit costs of its OWN rays
+ * (rt_scene_unit_costs over its nrecords rays, with the scene's "image_width" as it traces them) and this adds them up per
+ * square: a unit counts for the listed square that holds its first record (tile_ids / tile_first: the rank's squares and
+ * where each one's records start among the rank's, in record order).  square_costs[nsquares] is indexed by square number
+ * and only added to: zero it, let every rank add its own, sum the array over the ranks (rt_comm_sum_f64) and hand it to
+ * rt_shard_plan on every rank. */
+int rt_shard_square_costs(const uint32_t *unit_costs, size_t nunits, int image_width, size_t nrecords, const uint32_t *tile_ids,
+                          const uint32_t *tile_first, size_t ntiles, double *square_costs, size_t nsquares);
 /* For a list of squares: ray_index[] (nullable) = the row-major pixel / ray index (i + j * width) of every record, square
  * after square; tile_first[i] (nullable) = first_record + position of square i's first record -- the table
  * rt_scatter_tiles takes. */
@@ -307,6 +332,10 @@ int rt_shard_ray_indices(int width, int height, int tile, const uint32_t *tile_i
 int rt_comm_unique_id(uint8_t id_out[RT_COMM_ID_BYTES]);
 int rt_comm_create(const uint8_t id[RT_COMM_ID_BYTES], int nranks, int rank, int device, void **comm_out);
 void rt_comm_destroy(void *comm);
+
+/* values[i] := sum over the ranks of values[i] (host memory; ncclAllReduce on a stream of its own, waited for).  A collective:
+ * every rank calls it with the same n.  nranks = 1 leaves the values alone and needs no communicator. */
+int rt_comm_sum_f64(void *comm, int nranks, int device, double *values, size_t n);
 
 /* The exchange step of a sharded frame, enqueued on `stream` of every rank (call it on all ranks, like a collective):
  * every rank but `root` sends its records (mine_dev, rank_first_record[rank + 1] - rank_first_record[rank] of them,

@@ -93,6 +93,8 @@ def _load():
         "ray_scene_intersection": (i32, [vp, sz, vp, vp]),
         "rt_intersect_async": (i32, [vp, vp, sz, vp, vp, vp]),
         "rt_intersect_static": (i32, [vp, vp, sz, vp, vp, vp]),
+        "rt_intersect_compact": (i32, [vp, vp, sz, vp, sz, vp]),
+        "rt_trace_pass_bgra8": (i32, [vp, vp, vp, vp, sz, C.POINTER(C.c_float), u32, vp]),
         "rt_trace_pass": (i32, [vp, vp, vp, vp, sz, C.POINTER(C.c_float), u32, vp]),
         "rt_trace_primary": (i32, [vp, i32, i32, C.POINTER(C.c_float), vp, vp, vp]),
         "rt_scene_count_fetches": (i32, [vp, vp, sz, sz, C.POINTER(u64), vp]),
@@ -103,7 +105,9 @@ def _load():
         "rt_pack_bgra8": (i32, [i32, vp, sz, vp, vp]),
         "rt_pack_hits8": (i32, [i32, vp, sz, vp, vp]),
         "rt_composite_layers": (i32, [i32, vp, vp, sz, vp, vp, vp]),
-        "rt_shard_plan": (i32, [i32, i32, i32, i32, vp, vp, vp, vp]),
+        "rt_shard_plan": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+        "rt_shard_square_costs": (i32, [vp, sz, i32, sz, vp, vp, sz, vp, sz]),
+        "rt_comm_sum_f64": (i32, [vp, i32, i32, vp, sz]),
         "rt_shard_ray_indices": (i32, [i32, i32, i32, vp, sz, u32, vp, vp]),
         "rt_comm_unique_id": (i32, [vp]),
         "rt_comm_create": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
@@ -301,6 +305,11 @@ class Scene:
         _check(lib.rt_intersect_static(self._h, _ptr(rays_ptr), n, _ptr(hits_ptr), _ptr(hits16_ptr),
                                        C.c_void_p(stream) if stream else None))
 
+    def intersect_compact(self, rays_ptr, n, out_ptr, record_bytes, stream=0):
+        """Only a compact record per ray: 16 = {id, t, u, v}, 8 = {id, t}, 4 = {id} bytes."""
+        _check(lib.rt_intersect_compact(self._h, _ptr(rays_ptr), n, _ptr(out_ptr), record_bytes,
+                                        C.c_void_p(stream) if stream else None))
+
     def trace_primary(self, width, height, origin, hits_ptr=None, hits16_ptr=None, stream=0):
         o = (C.c_float * 3)(*[float(x) for x in origin])
         _check(lib.rt_trace_primary(self._h, width, height, o, _ptr(hits_ptr), _ptr(hits16_ptr),
@@ -310,6 +319,12 @@ class Scene:
         cam_arr = (C.c_float * 16)(*[float(x) for x in np.asarray(cam, dtype=np.float32).reshape(16)])
         _check(lib.rt_trace_pass(self._h, _ptr(rays_in_ptr), _ptr(rays_out_ptr), _ptr(rgba_ptr), n, cam_arr, op,
                                  C.c_void_p(stream) if stream else None))
+
+    def trace_pass_bgra8(self, rays_in_ptr, rays_out_ptr, bgra_ptr, n, cam, op, stream=0):
+        """rt_trace_pass with the pixel written as 8-bit BGRA (4 bytes per ray)."""
+        cam_arr = (C.c_float * 16)(*[float(x) for x in np.asarray(cam, dtype=np.float32).reshape(16)])
+        _check(lib.rt_trace_pass_bgra8(self._h, _ptr(rays_in_ptr), _ptr(rays_out_ptr), _ptr(bgra_ptr), n, cam_arr, op,
+                                       C.c_void_p(stream) if stream else None))
 
     def count_fetches(self, rays, stride=1, per_ray=False):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, RAY_FLOATS)
@@ -393,15 +408,32 @@ class ShardPlan:
     """rt_shard_plan: which squares of a width x height image (cut into tile x tile squares) each of `nranks` ranks traces.
     tiles[r] = rank r's squares in the order dealt; first_record[r] = where its records start in the gather buffer."""
 
-    def __init__(self, width, height, tile, nranks, unit_costs=None):
+    def __init__(self, width, height, tile, nranks, unit_costs=None, square_costs=None, head_start=None):
         self.width, self.height, self.tile, self.nranks = width, height, tile, nranks
         tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
         self.tile_order = np.zeros(tx * ty, np.uint32)
         self.first_tile = np.zeros(nranks + 1, np.uint64)
         self.first_record = np.zeros(nranks + 1, np.uint64)
         costs = None if unit_costs is None else np.ascontiguousarray(unit_costs, dtype=np.uint32)
-        _check(lib.rt_shard_plan(width, height, tile, nranks, _ptr(costs), _ptr(self.tile_order), _ptr(self.first_tile), _ptr(self.first_record)))
+        sq = None if square_costs is None else np.ascontiguousarray(square_costs, dtype=np.float64)
+        assert sq is None or len(sq) == tx * ty
+        hs = None if head_start is None else np.ascontiguousarray(head_start, dtype=np.float64)
+        assert hs is None or len(hs) == nranks
+        _check(lib.rt_shard_plan(width, height, tile, nranks, _ptr(costs), _ptr(sq), _ptr(hs), _ptr(self.tile_order), _ptr(self.first_tile),
+                                 _ptr(self.first_record)))
         self.tiles = [self.tile_order[int(self.first_tile[r]):int(self.first_tile[r + 1])] for r in range(nranks)]
+
+    def square_costs_of_rank(self, rank, unit_costs, image_width, out=None):
+        """rt_shard_square_costs: adds rank's own work-unit costs (of a launch over its records with the given image hint)
+        to a per-square array (all squares of the image; made here if not given)."""
+        tx, ty = (self.width + self.tile - 1) // self.tile, (self.height + self.tile - 1) // self.tile
+        out = np.zeros(tx * ty, np.float64) if out is None else out
+        t = np.ascontiguousarray(self.tiles[rank])
+        first = np.zeros(len(t), np.uint32)
+        _check(lib.rt_shard_ray_indices(self.width, self.height, self.tile, _ptr(t), len(t), 0, None, _ptr(first)))
+        u = np.ascontiguousarray(unit_costs, dtype=np.uint32).reshape(-1)
+        _check(lib.rt_shard_square_costs(_ptr(u), len(u), image_width, self.records(rank), _ptr(t), _ptr(first), len(t), _ptr(out), len(out)))
+        return out
 
     def records(self, rank):
         return int(self.first_record[rank + 1] - self.first_record[rank])
@@ -428,6 +460,12 @@ class Comm:
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(comm_id))
         _check(lib.rt_comm_create(buf, nranks, rank, device, C.byref(h)))
         self._h, self.nranks, self.rank, self.device = h, nranks, rank, device
+
+    def sum_f64(self, values):
+        """In place: values[i] := sum over the ranks (rt_comm_sum_f64; a collective)."""
+        assert values.dtype == np.float64 and values.flags.c_contiguous
+        _check(lib.rt_comm_sum_f64(self._h, self.nranks, self.device, _ptr(values), values.size))
+        return values
 
     @staticmethod
     def unique_id():

@@ -153,6 +153,7 @@ struct rt_scene {
   mutable uint32_t fb_launch = 0;
   mutable uint32_t fb_since_sort = 0;                       // launches since the last one that recorded costs
   mutable int fb_cur = 0, fb_newest = 0;                    // set the launches record into; set of the sort enqueued last
+  int side_stream = 1;                                      // 0: the order-building kernels run on the launch's own stream, behind the trace kernel
   int side_priority = 0;                                    // 1: the order-building side stream is created at the highest stream priority
   int feedback_period = 8;                                  // every this-many launches one records its costs and a sort follows it
   mutable hipStream_t side = nullptr;                       // the order-building kernel runs here, beside the next trace
@@ -259,6 +260,8 @@ int EnsureOrder(const rt_scene *s, uint32_t w, uint32_t h)
 int ResetFeedback(const rt_scene *s)
 {
   if (s->side) RT_HIP(hipStreamSynchronize(s->side));
+  for (int k = 0; k < 2; ++k)   // sorts that ran on a caller's stream
+    if (s->fb_pending[k] && s->ev_sort[k]) RT_HIP(hipEventSynchronize(s->ev_sort[k]));
   for (int k = 0; k < 2; ++k) {
     if (s->d_fb_cost[k]) (void)hipFree(s->d_fb_cost[k]);
     if (s->d_fb_order[k]) (void)hipFree(s->d_fb_order[k]);
@@ -365,7 +368,13 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
         RT_HIP(hipMemset(s->d_fb_cost[k], 0, padded * sizeof(uint32_t)));
         RT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_fb_order[k]), static_cast<size_t>(a.ntasks) * sizeof(uint32_t)));
       }
-      if (!s->side) {
+      if (!s->ev_sort[0]) {
+        for (int k = 0; k < 2; ++k) {
+          RT_HIP(hipEventCreateWithFlags(&s->ev_main[k], hipEventDisableTiming));
+          RT_HIP(hipEventCreateWithFlags(&s->ev_sort[k], hipEventDisableTiming));
+        }
+      }
+      if (!s->side && s->side_stream) {
         // The side stream must be NON-BLOCKING.  A stream created with default flags (which is what
         // hipStreamCreateWithPriority(&q, 0, prio) gives) synchronises implicitly with the legacy null stream: a trace launch
         // of a null-stream caller then waits for everything the side stream holds, and the side stream's head waits for that
@@ -381,10 +390,6 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
         unsigned side_flags = 0;
         RT_HIP(hipStreamGetFlags(s->side, &side_flags));
         if (!(side_flags & hipStreamNonBlocking)) return Fail(RT_ERR_DEVICE, "internal: the order-building stream is not non-blocking");
-        for (int k = 0; k < 2; ++k) {
-          RT_HIP(hipEventCreateWithFlags(&s->ev_main[k], hipEventDisableTiming));
-          RT_HIP(hipEventCreateWithFlags(&s->ev_sort[k], hipEventDisableTiming));
-        }
       }
       s->fb_ntasks = a.ntasks; s->fb_n = a.n; s->fb_img_w = a.img_w;
     }
@@ -444,7 +449,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
   }
   {
     hipError_t e_ = rt::LaunchClosestHit(a, s->width, s->quant != 0, mode, count, grid, block, stream,
-                                         sort_now ? s->ev_main[fb_slot] : nullptr);
+                                         sort_now && s->side_stream ? s->ev_main[fb_slot] : nullptr);
     if (e_ != hipSuccess)
       return Fail(RT_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(e_) + " (grid " + std::to_string(grid) +
                                      ", block " + std::to_string(block) + ", stack entries " + std::to_string(a.stack_entries) + ")");
@@ -462,12 +467,17 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     s->fb_have_last = true;
   }
   if (sort_now) {
-    // ev_main[fb_slot] is signalled by the trace kernel itself (its launch carried the event)
-    RT_HIP(hipStreamWaitEvent(s->side, s->ev_main[fb_slot], 0));
-    for (size_t k = 0; k < s->fb_left_used; ++k) RT_HIP(hipStreamWaitEvent(s->side, s->fb_left[k], 0));
+    // The sort runs behind this launch and behind whatever earlier launches of the period other streams still hold: on the
+    // side stream (ev_main[fb_slot] is signalled by the trace kernel itself, its launch carried the event), or, with
+    // "side_stream" 0, on the launch's own stream.  The second form costs that stream the sort's few microseconds but keeps
+    // the process to one stream per frame in flight: streams share the GPU's few hardware queues, and a side stream whose head
+    // waits for one frame's launch holds up every other stream that was mapped to the same queue.
+    hipStream_t sort_on = s->side_stream ? s->side : stream;
+    if (s->side_stream) RT_HIP(hipStreamWaitEvent(sort_on, s->ev_main[fb_slot], 0));
+    for (size_t k = 0; k < s->fb_left_used; ++k) RT_HIP(hipStreamWaitEvent(sort_on, s->fb_left[k], 0));
     s->fb_left_used = 0;
-    RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_bins, s->d_fb_order[fb_slot], s->side));
-    RT_HIP(hipEventRecord(s->ev_sort[fb_slot], s->side));
+    RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_bins, s->d_fb_order[fb_slot], sort_on));
+    RT_HIP(hipEventRecord(s->ev_sort[fb_slot], sort_on));
     s->fb_sorted[fb_slot] = s->fb_pending[fb_slot] = true;
     s->fb_newest = fb_slot;
     s->fb_cur = 1 - fb_slot;
@@ -761,11 +771,12 @@ void rt_scene_destroy(rt_scene *s)
   (void)hipFree(s->d_nodes2); (void)hipFree(s->d_nodes4); (void)hipFree(s->d_nodesq2); (void)hipFree(s->d_nodesq4); (void)hipFree(s->d_tris);
   (void)hipFree(s->d_verts); (void)hipFree(s->d_faces); (void)hipFree(s->d_normals); (void)hipFree(s->d_mats);
   (void)hipFree(s->d_stats); (void)hipFree(s->d_cursor); (void)hipFree(s->d_order); (void)ResetFeedback(s);
-  if (s->side) {
-    (void)hipStreamDestroy(s->side);
-    for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(s->ev_main[k]); (void)hipEventDestroy(s->ev_sort[k]); }
-    for (hipEvent_t e : s->fb_left) (void)hipEventDestroy(e);
+  if (s->side) (void)hipStreamDestroy(s->side);
+  for (int k = 0; k < 2; ++k) {
+    if (s->ev_main[k]) (void)hipEventDestroy(s->ev_main[k]);
+    if (s->ev_sort[k]) (void)hipEventDestroy(s->ev_sort[k]);
   }
+  for (hipEvent_t e : s->fb_left) (void)hipEventDestroy(e);
   (void)hipFree(s->d_stage_in); (void)hipFree(s->d_stage_out);
   for (int k = 0; k < 2; ++k) {
     if (s->pin_in[k]) (void)hipHostFree(s->pin_in[k]);
@@ -847,10 +858,19 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
       int rc = ResetFeedback(s);
       if (rc != RT_OK) return rc;
       (void)hipStreamDestroy(s->side);
-      for (int j = 0; j < 2; ++j) { (void)hipEventDestroy(s->ev_main[j]); (void)hipEventDestroy(s->ev_sort[j]); s->ev_main[j] = s->ev_sort[j] = nullptr; }
       s->side = nullptr;
     }
     s->side_priority = value;
+  } else if (k == "side_stream") {
+    if (value < 0 || value > 1) return Fail(RT_ERR_INVALID, "side_stream must be 0 or 1");
+    if (value != s->side_stream) {
+      DeviceGuard guard(s->device);
+      int rc = ResetFeedback(s);
+      if (rc != RT_OK) return rc;
+      if (s->side) (void)hipStreamDestroy(s->side);
+      s->side = nullptr;
+    }
+    s->side_stream = value;
   } else if (k == "refill") {
     if (value < 0 || value > 64) return Fail(RT_ERR_INVALID, "refill must be in 0..64");
     s->refill = value;
@@ -905,6 +925,29 @@ int rt_intersect_async(const rt_scene *s, const void *rays_dev, size_t n, void *
     a.rays = static_cast<const rt_ray_isect *>(rays_dev) + off;
     a.hits = hits_dev ? static_cast<rt_ray_isect *>(hits_dev) + off : nullptr;
     a.hits16 = hits16_dev ? static_cast<rt_hit16 *>(hits16_dev) + off : nullptr;
+    a.n = static_cast<uint32_t>(std::min(kChunk, n - off));
+    int rc = Enqueue(s, a, rt::kModeIntersect, false, static_cast<hipStream_t>(stream));
+    if (rc != RT_OK) return rc;
+  }
+  return RT_OK;
+}
+
+int rt_intersect_compact(const rt_scene *s, const void *rays_dev, size_t n, void *out_dev, size_t record_bytes, void *stream)
+{
+  if (!s) return Fail(RT_ERR_INVALID, "null scene");
+  if (s->device == RT_DEVICE_NONE) return Fail(RT_ERR_DEVICE, "scene was created without a device");
+  if (record_bytes != 4u && record_bytes != 8u && record_bytes != 16u)
+    return Fail(RT_ERR_INVALID, "compact records are 4 ({id}), 8 ({id, t}) or 16 ({id, t, u, v}) bytes");
+  if (n == 0) return RT_OK;
+  if (!rays_dev || !out_dev) return Fail(RT_ERR_INVALID, "null ray or hit buffer");
+  DeviceGuard guard(s->device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  for (size_t off = 0; off < n; off += kChunk) {
+    rt::KernelArgs a;
+    FillArgs(s, a);
+    a.rays = static_cast<const rt_ray_isect *>(rays_dev) + off;
+    a.hits16 = reinterpret_cast<rt_hit16 *>(static_cast<char *>(out_dev) + off * record_bytes);
+    a.compact_words = static_cast<uint32_t>(record_bytes / 4u);
     a.n = static_cast<uint32_t>(std::min(kChunk, n - off));
     int rc = Enqueue(s, a, rt::kModeIntersect, false, static_cast<hipStream_t>(stream));
     if (rc != RT_OK) return rc;
@@ -1195,9 +1238,25 @@ int ray_scene_intersection(const void *rays, size_t n, const rt_scene *scene, vo
   return RT_OK;
 }
 
+static int TracePass(const rt_scene *s, const void *rays_in_dev, void *rays_out_dev, void *pixels_dev, bool pixels8, size_t n,
+                     const float cam[16], unsigned trace_operation, void *stream);
+
 int rt_trace_pass(const rt_scene *s, const void *rays_in_dev, void *rays_out_dev, float *rgba_dev, size_t n,
                   const float cam[16], unsigned trace_operation, void *stream)
 {
+  return TracePass(s, rays_in_dev, rays_out_dev, rgba_dev, false, n, cam, trace_operation, stream);
+}
+
+int rt_trace_pass_bgra8(const rt_scene *s, const void *rays_in_dev, void *rays_out_dev, void *bgra_dev, size_t n,
+                        const float cam[16], unsigned trace_operation, void *stream)
+{
+  return TracePass(s, rays_in_dev, rays_out_dev, bgra_dev, true, n, cam, trace_operation, stream);
+}
+
+static int TracePass(const rt_scene *s, const void *rays_in_dev, void *rays_out_dev, void *pixels_dev, bool pixels8, size_t n,
+                     const float cam[16], unsigned trace_operation, void *stream)
+{
+  float *rgba_dev = static_cast<float *>(pixels_dev);
   if (!s) return Fail(RT_ERR_INVALID, "null scene");
   if (s->device == RT_DEVICE_NONE) return Fail(RT_ERR_DEVICE, "scene was created without a device");
   if (trace_operation > 1) return Fail(RT_ERR_INVALID, "trace_operation must be 0 or 1");
@@ -1212,7 +1271,8 @@ int rt_trace_pass(const rt_scene *s, const void *rays_in_dev, void *rays_out_dev
     FillArgs(s, a);
     a.rays = static_cast<const rt_ray_isect *>(rays_in_dev) + off;
     a.hits = rays_out_dev ? static_cast<rt_ray_isect *>(rays_out_dev) + off : nullptr;
-    a.rgba = rgba_dev ? rgba_dev + off * 4 : nullptr;
+    a.rgba = rgba_dev ? rgba_dev + off * (pixels8 ? 1 : 4) : nullptr;
+    a.pixels8 = pixels8 ? 1u : 0u;
     a.n = static_cast<uint32_t>(std::min(kChunk, n - off));
     a.op = trace_operation;
     if (cam) std::memcpy(a.cam, cam, sizeof a.cam);

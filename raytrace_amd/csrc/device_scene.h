@@ -51,6 +51,8 @@ struct KernelArgs {
   uint32_t split_units;       // the first this-many units of `order` are traced by four waves each, a quarter of the unit's rays per wave
   uint32_t coop;              // 1: the quarter waves of split units work four lanes per ray (four-wide quantized records; the tree's
                               // worst-case stack must fit 4 * stack_entries, the LDS columns of a quad)
+  uint32_t compact_words;     // what `hits16` receives per ray: 4 = {id, t, u, v} (also 0), 2 = {id, t}, 1 = {id}
+  uint32_t pixels8;           // kModeTrace, 1: `rgba` receives 8-bit BGRA pixels (4 bytes each) instead of RGBA32F
   uint32_t refill_min;        // RefillHitKernel: idle lanes of a wave that trigger handing out new rays
   uint32_t prio_slots;        // the first this-many dispatch slots run at raised issue priority (0 = none)
   uint32_t cost_radius;       // a unit's cost is also recorded for its neighbours within this many units (<= 3)

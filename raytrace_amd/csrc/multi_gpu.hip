@@ -30,6 +30,8 @@ constexpr int kNcclUniqueIdBytes = 128;
 struct NcclUniqueId { char internal[kNcclUniqueIdBytes]; };
 typedef void *NcclComm;
 constexpr int kNcclUint8 = 1;   // ncclUint8
+constexpr int kNcclFloat64 = 8; // ncclFloat64
+constexpr int kNcclSum = 0;     // ncclSum
 
 struct Rccl {
   void *lib = nullptr;
@@ -38,6 +40,7 @@ struct Rccl {
   int (*CommDestroy)(NcclComm) = nullptr;
   int (*Send)(const void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   int (*Recv)(void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
@@ -67,6 +70,7 @@ Rccl *LoadRccl()
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
     r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
     r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
@@ -131,11 +135,12 @@ __global__ void __launch_bounds__(256) CompositeKernel(const float4 *layer0, con
 
 extern "C" {
 
-int rt_shard_plan(int width, int height, int tile, int nranks, const uint32_t *unit_costs, uint32_t *tile_order,
-                  uint64_t *rank_first_tile, uint64_t *rank_first_record)
+int rt_shard_plan(int width, int height, int tile, int nranks, const uint32_t *unit_costs, const double *square_costs,
+                  const double *rank_head_start, uint32_t *tile_order, uint64_t *rank_first_tile, uint64_t *rank_first_record)
 {
   if (width <= 0 || height <= 0 || tile <= 0 || nranks <= 0 || !tile_order || !rank_first_tile || !rank_first_record)
     return RtFail(RT_ERR_INVALID, "bad shard plan arguments");
+  if (unit_costs && square_costs) return RtFail(RT_ERR_INVALID, "give the costs per work unit or per square, not both");
   if (unit_costs && tile % 8 != 0) return RtFail(RT_ERR_INVALID, "with a cost table the squares must be made of whole 8x8 work units");
   const uint32_t tx = (width + tile - 1) / tile, ty = (height + tile - 1) / tile, ntiles = tx * ty;
   auto pixels = [&](uint32_t k) {
@@ -143,19 +148,33 @@ int rt_shard_plan(int width, int height, int tile, int nranks, const uint32_t *u
     return static_cast<uint64_t>(std::min<uint32_t>(tile, width - x0)) * std::min<uint32_t>(tile, height - y0);
   };
   std::vector<std::vector<uint32_t>> lists(nranks);
-  if (!unit_costs) {
+  if (!unit_costs && !square_costs) {
     for (uint32_t k = 0; k < ntiles; ++k) lists[k % nranks].push_back(k);   // round-robin
   } else {
-    // the kernel's per-8x8-tile costs summed over each square; squares dealt costliest first, each to the rank with the least
-    // cost so far (ties: the lower rank); every square also carries a floor cost: its pixels are generated and stored whatever they hit
-    const uint32_t ux = (width + 7) / 8, uy = (height + 7) / 8, per = tile / 8;
+    // squares dealt costliest first, each to the rank with the least cost so far (ties: the lower rank); every square also
+    // carries a floor cost: its pixels are generated and stored whatever they hit
     std::vector<double> cost(ntiles, 0.0);
-    for (uint32_t j = 0; j < uy; ++j)
-      for (uint32_t i = 0; i < ux; ++i) cost[(j / per) * tx + i / per] += unit_costs[j * ux + i];
+    if (unit_costs) {   // the kernel's per-8x8-tile costs summed over each square
+      const uint32_t ux = (width + 7) / 8, uy = (height + 7) / 8, per = tile / 8;
+      for (uint32_t j = 0; j < uy; ++j)
+        for (uint32_t i = 0; i < ux; ++i) cost[(j / per) * tx + i / per] += unit_costs[j * ux + i];
+    } else {
+      for (uint32_t k = 0; k < ntiles; ++k) {
+        if (!(square_costs[k] >= 0.0)) return RtFail(RT_ERR_INVALID, "square costs must be non-negative numbers");
+        cost[k] = square_costs[k];
+      }
+    }
+    double total = 0.0;
+    for (uint32_t k = 0; k < ntiles; ++k) total += cost[k] + 1.0;
     std::vector<uint32_t> order(ntiles);
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
     std::vector<double> load(nranks, 0.0);
+    if (rank_head_start)
+      for (int r = 0; r < nranks; ++r) {
+        if (!(rank_head_start[r] >= 0.0)) return RtFail(RT_ERR_INVALID, "head starts must be non-negative numbers");
+        load[r] = rank_head_start[r] * total;
+      }
     for (uint32_t k : order) {
       const int r = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
       lists[r].push_back(k);
@@ -173,6 +192,30 @@ int rt_shard_plan(int width, int height, int tile, int nranks, const uint32_t *u
   }
   rank_first_tile[nranks] = t;
   rank_first_record[nranks] = rec;
+  return RT_OK;
+}
+
+int rt_shard_square_costs(const uint32_t *unit_costs, size_t nunits, int image_width, size_t nrecords, const uint32_t *tile_ids,
+                          const uint32_t *tile_first, size_t ntiles, double *square_costs, size_t nsquares)
+{
+  if (!unit_costs || !tile_ids || !tile_first || !square_costs || image_width < 0) return RtFail(RT_ERR_INVALID, "bad square cost arguments");
+  // the work units of a launch over nrecords rays, as the library cuts them: 8x8 blocks of an image_width-wide image, or
+  // runs of 64 records
+  const bool image = image_width > 0 && nrecords % static_cast<size_t>(image_width) == 0;
+  const size_t ux = image ? (static_cast<size_t>(image_width) + 7) / 8 : 0;
+  const size_t expect = image ? ux * ((nrecords / image_width + 7) / 8) : (nrecords + 63) / 64;
+  if (nunits != expect) return RtFail(RT_ERR_INVALID, "the cost table has " + std::to_string(nunits) + " work units, the ray set " + std::to_string(expect));
+  for (size_t i = 0; i < ntiles; ++i) {
+    if (tile_ids[i] >= nsquares) return RtFail(RT_ERR_INVALID, "square number out of range");
+    if (i && tile_first[i] < tile_first[i - 1]) return RtFail(RT_ERR_INVALID, "squares must be listed in record order");
+  }
+  for (size_t u = 0; u < nunits; ++u) {
+    // a unit counts for the square that holds its first record
+    const size_t rec = image ? (u / ux) * 8 * static_cast<size_t>(image_width) + (u % ux) * 8 : u * 64;
+    const uint32_t *hi = std::upper_bound(tile_first, tile_first + ntiles, static_cast<uint32_t>(std::min<size_t>(rec, 0xFFFFFFFFu)));
+    if (hi == tile_first) continue;   // before the first listed square
+    square_costs[tile_ids[hi - tile_first - 1]] += unit_costs[u];
+  }
   return RT_OK;
 }
 
@@ -262,6 +305,32 @@ void rt_comm_destroy(void *comm)
 {
   Rccl *r = LoadRccl();
   if (comm && r->CommDestroy) (void)r->CommDestroy(comm);
+}
+
+int rt_comm_sum_f64(void *comm, int nranks, int device, double *values, size_t n)
+{
+  if (nranks <= 0 || (n && !values)) return RtFail(RT_ERR_INVALID, "bad arguments");
+  if (nranks == 1 || n == 0) return RT_OK;
+  if (!comm) return RtFail(RT_ERR_INVALID, "a communicator is needed for more than one rank");
+  Rccl *r = LoadRccl();
+  if (!r->why.empty()) return RtFail(RT_ERR_DEVICE, r->why);
+  DeviceScope scope(device);
+  if (!scope.ok) return RtFail(RT_ERR_DEVICE, "hipSetDevice failed");
+  double *d = nullptr;
+  hipError_t he = hipMalloc(reinterpret_cast<void **>(&d), n * sizeof(double));
+  if (he != hipSuccess) return RtFail(RT_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(he));
+  hipStream_t q = nullptr;
+  int e = 0;
+  he = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipMemcpyAsync(d, values, n * sizeof(double), hipMemcpyHostToDevice, q);
+  if (he == hipSuccess) e = r->AllReduce(d, d, n, kNcclFloat64, kNcclSum, comm, q);
+  if (he == hipSuccess && e == 0) he = hipMemcpyAsync(values, d, n * sizeof(double), hipMemcpyDeviceToHost, q);
+  if (he == hipSuccess && e == 0) he = hipStreamSynchronize(q);
+  if (q) (void)hipStreamDestroy(q);
+  (void)hipFree(d);
+  if (e != 0) return FailNccl(r, e, "ncclAllReduce");
+  if (he != hipSuccess) return RtFail(RT_ERR_DEVICE, std::string("sum over ranks: ") + hipGetErrorString(he));
+  return RT_OK;
 }
 
 int rt_gather_scatter(void *comm, int rank, int nranks, int root, int device, const void *mine_dev, void *gather_dev,

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "../../include/rt_layout.h"
@@ -62,6 +63,35 @@ __device__ __forceinline__ void StoreStreamF4(float4 *p, const float4 v)
     return;
   }
   *p = v;
+}
+
+// The compact hit of record idx: {id, t, u, v}, or only its first two words or its first word ("compact" argument).
+template <bool STREAM>
+__device__ __forceinline__ void StoreCompactHit(const KernelArgs &p, uint32_t idx, uint32_t id, float t, float u, float v)
+{
+  if (p.compact_words == 2u) {
+    typedef uint32_t NativeU2 __attribute__((ext_vector_type(2)));
+    const NativeU2 w = {id, __float_as_uint(t)};
+    NativeU2 *dst = reinterpret_cast<NativeU2 *>(p.hits16) + idx;
+    if (RT_STREAM_NT && STREAM) __builtin_nontemporal_store(w, dst);
+    else *dst = w;
+  } else if (p.compact_words == 1u) {
+    uint32_t *dst = reinterpret_cast<uint32_t *>(p.hits16) + idx;
+    if (RT_STREAM_NT && STREAM) __builtin_nontemporal_store(id, dst);
+    else *dst = id;
+  } else {
+    StoreStreamF4<STREAM>(reinterpret_cast<float4 *>(p.hits16 + idx), make_float4(__uint_as_float(id), t, u, v));
+  }
+}
+
+// 8-bit BGRA of an RGBA32F pixel: each channel min(255, max(0, x * 255 + 0.5)) truncated, alpha 255 (the byte order a
+// 32-bit bitmap stores and the reference's writer passes through, cpu_raycast/bmp.h:12, bmp.c:49-53).
+__device__ __forceinline__ uint32_t PackBgra8(const float4 c)
+{
+  const uint32_t r = static_cast<uint32_t>(fminf(255.f, fmaxf(0.f, c.x * 255.f + 0.5f)));
+  const uint32_t g = static_cast<uint32_t>(fminf(255.f, fmaxf(0.f, c.y * 255.f + 0.5f)));
+  const uint32_t b = static_cast<uint32_t>(fminf(255.f, fmaxf(0.f, c.z * 255.f + 0.5f)));
+  return b | (g << 8) | (r << 16) | 0xFF000000u;
 }
 
 struct Best {
@@ -620,9 +650,7 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
         writer = !(q && p.coop != 0u) || (threadIdx.x & 3u) == 0u;
       }
       if (p.hits16 && writer) {
-        rt_hit16 h;
-        h.triangle_id = best.id; h.t = best.t; h.u = hit ? best.u : 0.f; h.v = hit ? best.v : 0.f;
-        StoreStreamF4<MODE != kModeTrace>(reinterpret_cast<float4 *>(p.hits16 + idx), make_float4(__uint_as_float(h.triangle_id), h.t, h.u, h.v));
+        StoreCompactHit<MODE != kModeTrace>(p, idx, best.id, best.t, hit ? best.u : 0.f, hit ? best.v : 0.f);
       }
       float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((p.hits || (MODE == kModeTrace && p.rgba)) && writer) {
@@ -673,7 +701,10 @@ __global__ void __launch_bounds__(256, MinWavesPerSimd(MODE)) ClosestHitKernel(K
         rec0 = out_o; rec1 = out_d; rec2 = out_n;
         rec3 = make_float4(out_u, out_v, __uint_as_float(best.id), best.t);
       }
-      if (MODE == kModeTrace && p.rgba) StoreStreamF4<MODE != kModeTrace>(reinterpret_cast<float4 *>(p.rgba) + idx, color);
+      if (MODE == kModeTrace && p.rgba && writer) {
+        if (p.pixels8) reinterpret_cast<uint32_t *>(p.rgba)[idx] = PackBgra8(color);
+        else StoreStreamF4<MODE != kModeTrace>(reinterpret_cast<float4 *>(p.rgba) + idx, color);
+      }
     }
     // After the traversal loop a SPLIT kernel works out again whether the wave holds a quarter, instead of carrying the answer
     // through the loop in registers the loop is short of.
@@ -915,9 +946,7 @@ __global__ void __launch_bounds__(256, kRefillWavesPerSimd) RefillHitKernel(Kern
       float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0, rec3 = rec0;
       if (retiring) {
         const bool hit = best.id != RT_MISS_ID;
-        if (p.hits16)
-          StoreStreamF4<true>(reinterpret_cast<float4 *>(p.hits16 + idx),
-                              make_float4(__uint_as_float(best.id), best.t, hit ? best.u : 0.f, hit ? best.v : 0.f));
+        if (p.hits16) StoreCompactHit<true>(p, idx, best.id, best.t, hit ? best.u : 0.f, hit ? best.v : 0.f);
         if (p.hits) HitRecord(p, best, make_float4(r.ox, r.oy, r.oz, ray_ow), make_float4(r.dx, r.dy, r.dz, ray_dw), rec0, rec1, rec2, rec3);
       }
       if (p.hits) RetireRecords(p, st.first, lane, retiring, idx, rec0, rec1, rec2, rec3);
@@ -1069,13 +1098,22 @@ __global__ void __launch_bounds__(64) OrderScatterKernel(uint32_t *unit_cost, ui
 
 // Tile-major records -> row-major framebuffer.  Tile i of the list covers the pixel block of tile_ids[i] in a W x H image
 // cut into `tile`-sized squares (edge tiles are smaller); its records, row-major inside the block, start at record
-// tile_first[i] of `src`.  One workgroup per tile; a record is `pieces` elements of PIECE (16 bytes, or 4 bytes for records
-// that are not a multiple of 16 such as 8-bit pixels), consecutive threads move consecutive pieces, so both sides are read
-// and written in runs of a tile row.
+// tile_first[i] of `src`.  gridDim.x = tiles, gridDim.y = workgroups that share a tile (large squares).  Consecutive threads
+// move consecutive pieces of a tile row, 16 bytes each when the rows on both sides are 16-byte aligned (else 4 bytes), so
+// both sides are read and written in runs of a tile row.
 template <typename PIECE>
-__global__ void __launch_bounds__(256) ScatterTilesKernel(const PIECE *src, uint32_t src_records, const uint32_t *tile_ids,
+__device__ __forceinline__ void MoveTileRows(const char *from, char *to, uint32_t row_bytes, uint32_t h, size_t pitch_bytes)
+{
+  const uint32_t row_pieces = row_bytes / static_cast<uint32_t>(sizeof(PIECE)), total = row_pieces * h;
+  for (uint32_t k = threadIdx.x + blockIdx.y * blockDim.x; k < total; k += blockDim.x * gridDim.y) {
+    const uint32_t row = k / row_pieces, col = k - row * row_pieces;
+    reinterpret_cast<PIECE *>(to + row * pitch_bytes)[col] = reinterpret_cast<const PIECE *>(from)[k];
+  }
+}
+
+__global__ void __launch_bounds__(256) ScatterTilesKernel(const char *src, uint32_t src_records, const uint32_t *tile_ids,
                                                           const uint32_t *tile_first, uint32_t tile, uint32_t img_w, uint32_t img_h,
-                                                          uint32_t pieces, PIECE *dst)
+                                                          uint32_t record_bytes, char *dst)
 {
   const uint32_t tiles_x = (img_w + tile - 1u) / tile, tiles_y = (img_h + tile - 1u) / tile;
   const uint32_t id = tile_ids[blockIdx.x];
@@ -1083,13 +1121,14 @@ __global__ void __launch_bounds__(256) ScatterTilesKernel(const PIECE *src, uint
   const uint32_t ty = id / tiles_x, tx = id - ty * tiles_x;
   const uint32_t x0 = tx * tile, y0 = ty * tile;
   const uint32_t w = min(tile, img_w - x0), h = min(tile, img_h - y0);
-  if (static_cast<uint64_t>(tile_first[blockIdx.x]) + static_cast<uint64_t>(w) * h > src_records) return;   // nor one that runs off src
-  const uint32_t row_pieces = w * pieces, total = row_pieces * h;
-  const PIECE *from = src + static_cast<size_t>(tile_first[blockIdx.x]) * pieces;
-  for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) {
-    const uint32_t row = k / row_pieces, col = k - row * row_pieces;
-    dst[(static_cast<size_t>(y0 + row) * img_w + x0) * pieces + col] = from[k];
-  }
+  const uint32_t first = tile_first[blockIdx.x];
+  if (static_cast<uint64_t>(first) + static_cast<uint64_t>(w) * h > src_records) return;   // nor one that runs off src
+  const size_t from_off = static_cast<size_t>(first) * record_bytes, pitch = static_cast<size_t>(img_w) * record_bytes;
+  const size_t to_off = (static_cast<size_t>(y0) * img_w + x0) * record_bytes;
+  const uint32_t row_bytes = w * record_bytes;
+  const bool wide = ((from_off | pitch | to_off | row_bytes | reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) & 15u) == 0u;
+  if (wide) MoveTileRows<uint4>(src + from_off, dst + to_off, row_bytes, h, pitch);
+  else MoveTileRows<uint32_t>(src + from_off, dst + to_off, row_bytes, h, pitch);
 }
 
 // RGBA32F pixels -> 8-bit BGRA, the byte order a 32-bit bitmap stores and the reference's writer passes through
@@ -1099,11 +1138,7 @@ __global__ void __launch_bounds__(256) PackPixelsKernel(const float4 *rgba, uint
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float4 c = rgba[i];
-  const uint32_t r = static_cast<uint32_t>(fminf(255.f, fmaxf(0.f, c.x * 255.f + 0.5f)));
-  const uint32_t g = static_cast<uint32_t>(fminf(255.f, fmaxf(0.f, c.y * 255.f + 0.5f)));
-  const uint32_t b = static_cast<uint32_t>(fminf(255.f, fmaxf(0.f, c.z * 255.f + 0.5f)));
-  bgra[i] = b | (g << 8) | (r << 16) | 0xFF000000u;
+  bgra[i] = PackBgra8(rgba[i]);
 }
 
 __global__ void TriBatchKernel(const rt_vec3 *tri, const rt_ray *ray, uint32_t n, int32_t *hit, float *t, rt_vec2 *uv)
@@ -1205,12 +1240,11 @@ hipError_t LaunchScatterTiles(const void *src, uint32_t src_records, const uint3
                               uint32_t tile, uint32_t img_w, uint32_t img_h, uint32_t record_bytes, void *dst, hipStream_t stream)
 {
   (void)hipGetLastError();
-  if (record_bytes % 16u == 0u)
-    hipLaunchKernelGGL(ScatterTilesKernel<uint4>, dim3(ntiles), dim3(256), 0, stream, static_cast<const uint4 *>(src), src_records, tile_ids,
-                       tile_first, tile, img_w, img_h, record_bytes / 16u, static_cast<uint4 *>(dst));
-  else
-    hipLaunchKernelGGL(ScatterTilesKernel<uint32_t>, dim3(ntiles), dim3(256), 0, stream, static_cast<const uint32_t *>(src), src_records, tile_ids,
-                       tile_first, tile, img_w, img_h, record_bytes / 4u, static_cast<uint32_t *>(dst));
+  // workgroups per square: about 16 KB of records each
+  const uint64_t tile_bytes = static_cast<uint64_t>(tile) * tile * record_bytes;
+  const uint32_t parts = static_cast<uint32_t>(std::min<uint64_t>(64u, std::max<uint64_t>(1u, tile_bytes / 16384u)));
+  hipLaunchKernelGGL(ScatterTilesKernel, dim3(ntiles, parts), dim3(256), 0, stream, static_cast<const char *>(src), src_records, tile_ids,
+                     tile_first, tile, img_w, img_h, record_bytes, static_cast<char *>(dst));
   return hipGetLastError();
 }
 

@@ -41,16 +41,20 @@ def tile_costs_from_units(unit_costs, width, height, tile):
     return out.reshape(-1)
 
 
-def assign_tiles(ntiles, world, costs=None):
+def assign_tiles(ntiles, world, costs=None, head_start=None):
     """Per-rank lists of square numbers.  With `costs` (one per square): longest-processing-time-first greedy --
     costliest square to the least-loaded rank (ties: lower rank), each rank's list in the order it was dealt
-    (costliest first, which is also the order its waves should start in).  Without: round-robin."""
+    (costliest first, which is also the order its waves should start in).  head_start[r] (optional) is the share
+    of the whole frame's cost rank r counts as carrying before the deal.  Without costs: round-robin."""
     if costs is None:
         return [np.arange(r, ntiles, world, dtype=np.int64) for r in range(world)]
     costs = np.asarray(costs, dtype=np.float64)
     assert len(costs) == ntiles
     order = np.argsort(-costs, kind="stable")
-    load = np.zeros(world)
+    total = 0.0
+    for k in range(ntiles):
+        total += costs[k] + 1.0
+    load = np.zeros(world) if head_start is None else np.asarray(head_start, dtype=np.float64) * total
     lists = [[] for _ in range(world)]
     for k in order:
         # every square carries a floor cost (its pixels have to be generated and stored even if nothing is hit)

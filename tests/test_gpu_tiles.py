@@ -208,3 +208,85 @@ def test_device_composite_equals_the_host_blend(rt, gpu):
     rt.composite_layers(gpu, a.data_ptr(), None, n, out.data_ptr(), None)
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), l0)
+
+
+def test_compact_records_and_8_bit_pixels_written_by_the_trace_kernel(rt, gpu):
+    """rt_intersect_compact writes the 16-, 8- or 4-byte head of the compact hit; rt_trace_pass_bgra8 writes the pixel as
+    8-bit BGRA.  Both must be the same bits as the two-step forms (rt_intersect_async's 16-byte record cut down,
+    rt_trace_pass + rt_pack_bgra8), for the plain launch, the cost-sorted launch with split and cooperative quarter waves
+    (from the third launch on) and the lane-refilling kernel; nothing is written past the records asked for."""
+    import torch
+    W, H = 611, 347
+    for model, loader in (("dragon.obj", "tolerant"), ("cube_mirror_test.obj", "reference")):
+        mesh = rt.Mesh.load_obj(os.path.join(MODELS, model), loader)
+        bvh = rt.BVH(mesh, "fixed")
+        rays = rt.primary_rays(W, H, rt.frame_camera(bvh.root_box, W, H))
+        n = W * H
+        scene = rt.Scene(mesh, bvh, device=gpu, width=4)
+        try:
+            scene.set_param("width", 4)
+            scene.set_param("image_width", W)
+            scene.set_param("feedback_period", 2)
+            rays_d = torch.from_numpy(rays).cuda()
+            want = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+            scene.intersect_async(rays_d.data_ptr(), n, None, want.data_ptr())
+            torch.cuda.synchronize()
+            for rec in (16, 8, 4):
+                for rep in range(4):
+                    out = torch.full((n + 8, rec // 4), -7, dtype=torch.int32, device="cuda")
+                    scene.intersect_compact(rays_d.data_ptr(), n, out.data_ptr(), rec)
+                    torch.cuda.synchronize()
+                    assert torch.equal(out[:n], want[:, :rec // 4]), (model, rec, rep)
+                    assert bool((out[n:] == -7).all())
+            with pytest.raises(rt.RtError):
+                scene.intersect_compact(rays_d.data_ptr(), n, out.data_ptr(), 12)
+            # pixels
+            rgba = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+            px_want = torch.zeros(n, dtype=torch.int32, device="cuda")
+            cam = np.eye(4, dtype=np.float32)
+            scene.trace_pass(rays_d.data_ptr(), None, rgba.data_ptr(), n, cam, 0)
+            rt.pack_bgra8(gpu, rgba.data_ptr(), n, px_want.data_ptr())
+            px = torch.full((n + 8,), -7, dtype=torch.int32, device="cuda")
+            recs = torch.zeros((n, 16), dtype=torch.float32, device="cuda")
+            recs_want = torch.zeros((n, 16), dtype=torch.float32, device="cuda")
+            scene.trace_pass(rays_d.data_ptr(), recs_want.data_ptr(), None, n, cam, 0)
+            scene.trace_pass_bgra8(rays_d.data_ptr(), recs.data_ptr(), px.data_ptr(), n, cam, 0)
+            torch.cuda.synchronize()
+            assert torch.equal(px[:n], px_want) and bool((px[n:] == -7).all())
+            assert torch.equal(recs.view(torch.int32), recs_want.view(torch.int32))
+            if model == "cube_mirror_test.obj":
+                assert len(torch.unique(px_want)) > 2
+            # the lane-refilling kernel (linear ray set, no image hint)
+            scene.set_param("image_width", 0)
+            scene.set_param("refill", 40)
+            for rec in (8, 4):
+                out = torch.full((n + 8, rec // 4), -7, dtype=torch.int32, device="cuda")
+                scene.intersect_compact(rays_d.data_ptr(), n, out.data_ptr(), rec)
+                torch.cuda.synchronize()
+                assert torch.equal(out[:n], want[:, :rec // 4]) and bool((out[n:] == -7).all())
+        finally:
+            scene.close()
+
+
+def test_scatter_of_large_squares_and_unaligned_tables(rt, gpu):
+    """rt_scatter_tiles with squares large enough to be shared by several workgroups, with 4-, 8- and 16-byte records, and with
+    a record table whose squares start at positions that are not multiples of 16 bytes (the 4-byte path)."""
+    import torch
+    from raytrace_amd.tiles import rays_of_tiles, tile_grid
+    rng = np.random.default_rng(11)
+    for W, H, tile in ((1024, 520, 256), (1001, 333, 128), (640, 360, 64)):
+        tx, ty = tile_grid(W, H, tile)
+        order = rng.permutation(tx * ty)
+        idx, first = rays_of_tiles(W, H, tile, order)
+        for words in (1, 2, 4):
+            img = torch.from_numpy(rng.integers(-2**31, 2**31 - 1, (W * H, words), dtype=np.int64).astype(np.int32)).cuda()
+            for shift in (0, 3):     # the table displaced by three records: unaligned starts for the small records
+                stacked = torch.zeros((W * H + shift, words), dtype=torch.int32, device="cuda")
+                stacked[shift:] = img[torch.from_numpy(idx).cuda()]
+                ids_d = torch.from_numpy(order.astype(np.int32)).cuda()
+                first_d = torch.from_numpy((first.astype(np.int64) + shift).astype(np.int32)).cuda()
+                fb = torch.zeros_like(img)
+                rt.scatter_tiles(gpu, stacked.data_ptr(), W * H + shift, ids_d.data_ptr(), first_d.data_ptr(), len(order), tile, W, H, 4 * words,
+                                 fb.data_ptr())
+                torch.cuda.synchronize()
+                assert torch.equal(fb, img), (W, H, tile, words, shift)

@@ -109,8 +109,43 @@ def test_library_shard_plan_equals_the_python_module(rt):
                     base += len(idx)
                     at += len(tf)
                 assert base == w * h and int(plan.first_record[world]) == w * h
+    # per-square costs and head starts: the same deal as the host mirror; a head start takes work off that rank
+    w, h, tile = 640, 360, 64
+    tx, ty = tile_grid(w, h, tile)
+    sq = rng.uniform(0, 5000, tx * ty)
+    for world in (2, 8):
+        for hs in (None, np.array([0.05] + [0.0] * (world - 1))):
+            plan = rt.ShardPlan(w, h, tile, world, None, sq, hs)
+            want = assign_tiles(tx * ty, world, sq, hs)
+            for r in range(world):
+                assert np.array_equal(plan.tiles[r].astype(np.int64), want[r]), (world, r)
+        even, less = rt.ShardPlan(w, h, tile, world, None, sq), rt.ShardPlan(w, h, tile, world, None, sq, hs)
+        # rank 0 ends up with about head start x total x (1 - 1/world) less than its even share
+        assert sq[less.tiles[0]].sum() < sq[even.tiles[0]].sum() - 0.4 * 0.05 * sq.sum() * (1 - 1 / world)
+    # a rank's own work-unit costs summed per square (image hint = the square's side, and the linear form), all ranks added
+    # up, equal the per-square sums of the whole image's table
+    units = rng.integers(0, 300, (h // 8, w // 8)).astype(np.uint32)
+    want_sq = tile_costs_from_units(units, w, h, tile)
+    for world in (1, 3):
+        plan = rt.ShardPlan(w, h, tile, world, units)
+        got = np.zeros(tx * ty)
+        for r in range(world):
+            # the rank's launch sees its squares stacked: an image `tile` wide whose 8x8 blocks are the original ones
+            idx = plan.ray_indices(r).astype(np.int64)
+            stacked_units = units[(idx // w) // 8, (idx % w) // 8].reshape(-1, tile)[::8, ::8].reshape(-1)
+            plan.square_costs_of_rank(r, stacked_units, tile, got)
+        assert np.array_equal(got, want_sq)
+        lin = plan.square_costs_of_rank(0, np.ones((plan.records(0) + 63) // 64, np.uint32), 0)
+        assert lin.sum() == (plan.records(0) + 63) // 64 and np.array_equal(lin[plan.tiles[0]], [min(tile, h - (k // tx) * tile) * tile // 64 for k in plan.tiles[0]])
+    c = rt.Comm.__new__(rt.Comm)
+    c._h, c.nranks, c.rank, c.device = None, 1, 0, 0
+    v = np.array([1.5, 2.5])
+    assert np.array_equal(c.sum_f64(v), [1.5, 2.5])          # one rank: the values themselves, no communicator, no GPU
     # bad arguments are errors, not crashes
-    assert rt.lib.rt_shard_plan(0, 10, 8, 1, None, None, None, None) == -1
+    assert rt.lib.rt_shard_plan(0, 10, 8, 1, None, None, None, None, None, None) == -1
+    bad = np.zeros(tx * ty, np.uint32), np.zeros(world + 1, np.uint64), np.zeros(world + 1, np.uint64)
+    assert rt.lib.rt_shard_plan(w, h, tile, world, rt._ptr(units), rt._ptr(sq), None, *[rt._ptr(b) for b in bad]) == -1
+    assert rt.lib.rt_shard_plan(w, h, tile, world, None, rt._ptr(-sq), None, *[rt._ptr(b) for b in bad]) == -1
     out = np.zeros(4, np.uint32)
     assert rt.lib.rt_shard_ray_indices(64, 64, 32, rt._ptr(np.array([9], np.uint32)), 1, 0, rt._ptr(out), None) == -1
 
