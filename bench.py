@@ -130,6 +130,15 @@ def newest_profile_table(name):
     return {}, None
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources (as tools/collect_profiles.py stamps the counter tables it writes)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("trace_kernels.hip", "trace_math.h"):
+        h.update(open(os.path.join(ROOT, "raytrace_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def timed(dist, steps, fn, finish=None):
     """Runs fn() `steps` times (then finish(), which completes what the steps left in flight) between barriers; returns
     (wall seconds, device ms per step by events on the current stream)."""
@@ -348,14 +357,25 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(rt.Comm.unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
-        comm = rt.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local)
+        ok = torch.ones(1, dtype=torch.int32, device=red_dev)
+        try:
+            comm = rt.Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local)
+        except rt.RtError as e:      # reported, and the job goes on through torch.distributed's own RCCL communicator
+            extra["rt_comm_create_failed"] = str(e)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
 
     def sum_over_ranks(values):
         """In place, float64 host array: the sum over the job's ranks (RCCL through the library; gloo in the rehearsal)."""
         if comm is not None:
             comm.sum_f64(values)
         elif dist:
-            dist.all_reduce(torch.from_numpy(values))
+            t = torch.from_numpy(values).to(red_dev)
+            dist.all_reduce(t)
+            values[...] = t.cpu().numpy()
         return values
 
     def share_rays(plan, r):
@@ -484,7 +504,7 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         lo = int(first_record[me])
         mine = [g[lo:lo + n_local] for g in gather] if root else [records(n_local) for _ in range(NB)]   # root traces into its slice
         host_in = [torch.empty((int(first_record[r + 1] - first_record[r]), rec_b // 4), dtype=torch.int32) for r in range(world)] \
-            if (world > 1 and comm is None and root) else None
+            if (world > 1 and comm is None and root and a.backend == "gloo") else None
         state = types.SimpleNamespace(frame=0, last=None, fresh=True)
 
         def trace_into(b):
@@ -493,10 +513,16 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         def exchange(b):
             q = raw(b)
             if world > 1 and comm is None:
-                # rehearsal backend (gloo): through host memory, synchronously; the scatter is still the library's
+                # without the library's communicator: through torch.distributed (gloo rehearsal: host memory, synchronously; nccl:
+                # its own RCCL communicator, grouped point-to-point); the scatter is still the library's
                 ctx = torch.cuda.stream(streams[b]) if streams else contextlib.nullcontext()
                 with ctx:
-                    if root:
+                    if a.backend == "nccl":
+                        ops = [dist.P2POp(dist.irecv, gather[b][int(first_record[r]):int(first_record[r + 1])], r) for r in range(1, world)] \
+                            if root else [dist.P2POp(dist.isend, mine[b], 0)]
+                        for w in dist.batch_isend_irecv(ops):
+                            w.wait()       # makes the current stream wait, not the host
+                    elif root:
                         for r in range(1, world):
                             dist.recv(host_in[r], src=r)
                             gather[b][int(first_record[r]):int(first_record[r + 1])].copy_(host_in[r])
@@ -635,7 +661,9 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
     extra["streams"] = sh.nstreams
     extra["launch_orders_built_on"] = "a side stream per scene" if sh.side else "the frame's own stream"
     extra["exchange"] = ("rt_gather_scatter over an RCCL communicator made by rt_comm_create" if comm is not None else
-                         ("rt_gather_scatter, one rank" if world == 1 else "gloo through host memory (rehearsal) + rt_gather_scatter for the scatter"))
+                         ("rt_gather_scatter, one rank" if world == 1 else
+                          ("gloo through host memory (rehearsal)" if a.backend == "gloo" else "torch.distributed batch_isend_irecv (the library's communicator "
+                           "could not be made)") + " + rt_gather_scatter for the scatter"))
     if sh.frames_in_flight >= 1:
         ms_1 = run(solo, sub, 2)
         extra["same_steps_one_frame_at_a_time"] = {"ms_per_step": round(ms_1, 4), "value": round(n_total / (ms_1 * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
@@ -924,6 +952,16 @@ def main():
         key = f"{workload}/{a.bvh}/w{width}/out{out_b}/{a.raygen}" + ("/refill" if refill_on else "")
         pmc_table, pmc_src = newest_profile_table("pmc_table.json")
         pmc = pmc_table.get(key) if world == 1 else None
+        # counters count for the kernels they were measured on: a table stamped with another source hash (or none) is named
+        # but not used, and the line falls back to the byte roofline
+        counters_head = None
+        if pmc:
+            stamp = pmc.get("code") or {}
+            counters_head = {"git": stamp.get("git"), "kernel_source_sha256": stamp.get("kernel_source_sha256"),
+                             "tree_kernel_source_sha256": kernel_source_hash()}
+            counters_head["current"] = counters_head["kernel_source_sha256"] == counters_head["tree_kernel_source_sha256"]
+            if not counters_head["current"]:
+                pmc = None
         peaks, _ = newest_profile_table("l2_gather_peak.json")
         res = {"hbm": {"achieved": round(stream_b * n_local / secs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "what": f"compulsory streams: {in_b} B ray in + {out_b} B hit out"}}
@@ -954,7 +992,7 @@ def main():
         roofline = {
             "bound": bound, "achieved": res[bound]["achieved"], "peak": res[bound]["peak"], "unit": res[bound]["unit"],
             "frac": res[bound]["frac"], "traffic": traffic, "traffic_unit": "GB per launch, HBM side (2 x FETCH_SIZE + WRITE_SIZE)",
-            "resources": res, "counters_from": pmc_src if pmc else None, "counters_key": key,
+            "resources": res, "counters_from": pmc_src if pmc else None, "counters_key": key, "counters_head": counters_head,
             "kernel": "RefillHitKernel" if refill_on else "ClosestHitKernel", "kernel_ms": round(dev_ms, 4),
             # the algorithmic traversal figure, never compared with the HBM peak: most of it is served by L1/L2
             "algorithmic": {"bytes_per_ray": round(stream_b + trav_b, 1), "stream_bytes_per_ray": stream_b,

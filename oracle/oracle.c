@@ -7,7 +7,7 @@
  *
  * Parity pin: every function here is checked bit-for-bit against the
  * reference's own core/ray_tri.cpp and core/raymath.cpp compiled from
- * /root/reference into oracle/_ref (tests/test_oracle_vs_ref.py, random pairs
+ * /root/reference into oracle/_ref (tests/test_oracle.py, random pairs
  * plus edge cases) and against the one known-answer test the reference holds
  * (cpu_raycast/raycast.cpp:12-19).
  *

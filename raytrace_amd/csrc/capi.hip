@@ -153,6 +153,7 @@ struct rt_scene {
   mutable uint32_t fb_launch = 0;
   mutable uint32_t fb_since_sort = 0;                       // launches since the last one that recorded costs
   mutable int fb_cur = 0, fb_newest = 0;                    // set the launches record into; set of the sort enqueued last
+  int model_width = 0;                                      // rt_scene_wave_model only: 8 = price an eight-wide collapse of the tree
   int side_stream = 1;                                      // 0: the order-building kernels run on the launch's own stream, behind the trace kernel
   int side_priority = 0;                                    // 1: the order-building side stream is created at the highest stream priority
   int feedback_period = 8;                                  // every this-many launches one records its costs and a sort follows it
@@ -861,6 +862,9 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
       s->side = nullptr;
     }
     s->side_priority = value;
+  } else if (k == "model_width") {
+    if (value != 0 && value != 8) return Fail(RT_ERR_INVALID, "model_width must be 0 (as traced) or 8");
+    s->model_width = value;
   } else if (k == "side_stream") {
     if (value < 0 || value > 1) return Fail(RT_ERR_INVALID, "side_stream must be 0 or 1");
     if (value != s->side_stream) {
@@ -1299,7 +1303,7 @@ int rt_scene_wave_model(const rt_scene *s, const rt_ray_isect *rays_host, size_t
 {
   if (!s || !rays_host || !out) return Fail(RT_ERR_INVALID, "null argument");
   if (image_width && n % image_width) return Fail(RT_ERR_INVALID, "ray count is not a multiple of image_width");
-  rt::WaveModel m = rt::SimulateWaves(s->flat, s->width, s->quant != 0, rays_host, n, image_width, refill, max_waves, policy);
+  rt::WaveModel m = rt::SimulateWaves(s->flat, s->model_width == 8 ? 8 : s->width, s->quant != 0, rays_host, n, image_width, refill, max_waves, policy);
   out[0] = m.waves; out[1] = m.rays; out[2] = m.wave_node_steps; out[3] = m.lane_node_steps; out[4] = m.wave_tri_steps;
   out[5] = m.lane_tri_steps; out[6] = m.wave_leaf_phases; out[7] = m.lane_leaf_phases; out[8] = m.refills; out[9] = m.refill_lanes; out[10] = m.max_wave_steps; out[11] = m.uniform_node_steps;
   out[12] = m.iterations; out[13] = m.max_wave_iterations; out[14] = m.two_node_steps; out[15] = m.three_node_steps;

@@ -205,7 +205,31 @@ inline int TestNodeHost(FlatScene const &fs, int width, bool quant, const RayCtx
                         uint32_t *hit_ref, float *hit_t)
 {
   int nh = 0;
-  if (quant) {
+  if (width == 8) {
+    // An eight-wide node that does not exist as a record: the two-wide node `cur` with its descendants three levels down
+    // (leaves stop the descent earlier), boxes from the quantized two-wide records.  What a node built by collapsing three
+    // levels of the binary tree would hold; for the wave model only.
+    GpuChildQ const *cand[8];
+    int nc = 0;
+    uint32_t level[4] = {cur, 0, 0, 0};
+    int nlevel = 1;
+    for (int depth = 0; depth < 3; ++depth) {
+      uint32_t next[8];
+      int nnext = 0;
+      for (int i = 0; i < nlevel; ++i)
+        for (int k = 0; k < 2; ++k) {
+          GpuChildQ const *c = fs.nodesq2.data() + static_cast<size_t>(level[i]) * 2 + k;
+          if ((c->ref & kLeafBit) || depth == 2) cand[nc++] = c;
+          else next[nnext++] = c->ref;
+        }
+      nlevel = nnext;
+      for (int i = 0; i < nnext; ++i) level[i] = next[i];
+    }
+    for (int i = 0; i < nc; ++i) {
+      float te;
+      if (SlabTestQ(rq, cand[i]->x, cand[i]->y, cand[i]->z, tbest, te)) { hit_ref[nh] = cand[i]->ref; hit_t[nh++] = te; }
+    }
+  } else if (quant) {
     const int w = width == 4 ? 4 : 2;
     GpuChildQ const *c = (w == 4 ? fs.nodesq4.data() : fs.nodesq2.data()) + static_cast<size_t>(cur) * w;
     for (int i = 0; i < w; ++i) {
@@ -393,7 +417,7 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
         for (auto &l : lanes) {
           if (l.cur == kDoneRef) continue;
           if (!(l.cur & kLeafBit)) {
-            uint32_t hit_ref[4]; float hit_t[4];
+            uint32_t hit_ref[8]; float hit_t[8];
             const int nh = TestNodeHost(fs, width, quant, l.r, l.rq, l.cur, l.tbest, hit_ref, hit_t);
             l.cur = DescendHost(l.stack, hit_ref, hit_t, nh, l.tbest);
             continue;
@@ -452,7 +476,7 @@ WaveModel SimulateWaves(FlatScene const &fs, int width, bool quant, rt_ray_isect
         }
         for (auto &l : lanes) {
           if (l.cur & kLeafBit) continue;
-          uint32_t hit_ref[4]; float hit_t[4];
+          uint32_t hit_ref[8]; float hit_t[8];
           const int nh = TestNodeHost(fs, width, quant, l.r, l.rq, l.cur, l.tbest, hit_ref, hit_t);
           l.cur = DescendHost(l.stack, hit_ref, hit_t, nh, l.tbest);
         }

@@ -1,9 +1,9 @@
 // rt_headless -- headless stand-in for the reference's windowed client
 // (render_client/img_main.cpp): loads a model, builds the BVH, creates the device scene, runs
 // the two passes of one frame (primary rays, then one reflection bounce, img_main.cpp:447-498),
-// composites the two RGBA32F layers the way gl_update blends its two textures
-// (img_main.cpp:434,512-526: layer 0 opaque, layer 1 with SRC_ALPHA / ONE_MINUS_DST_ALPHA) and
-// writes a BMP instead of presenting a window.
+// composites the two RGBA32F layers on the device the way gl_update blends its two textures
+// (rt_composite_layers; img_main.cpp:434,512-526: layer 0 opaque, layer 1 with SRC_ALPHA / ONE_MINUS_DST_ALPHA),
+// downloads the 8-bit frame and writes a BMP instead of presenting a window.
 //
 //   rt_headless [--model PATH] [--width W] [--height H] [--loader reference|tolerant]
 //               [--bvh reference|fixed|sah] [--wide 2|4] [--bounces N] [--device D] [--out FILE.bmp]
@@ -80,50 +80,39 @@ int main(int argc, char **argv)
   CHECK(rt_primary_rays(W, H, origin, rays.data()));
 
   HIPCHECK(hipSetDevice(device));
-  void *d_cam = nullptr, *d_a = nullptr, *d_b = nullptr;
-  float *d_rgba = nullptr;
+  void *d_cam = nullptr, *d_a = nullptr, *d_b = nullptr, *d_bgra = nullptr;
+  float *d_frame = nullptr, *d_layer = nullptr;
   HIPCHECK(hipMalloc(&d_cam, n * sizeof(rt_ray_isect)));
   HIPCHECK(hipMalloc(&d_a, n * sizeof(rt_ray_isect)));
   HIPCHECK(hipMalloc(&d_b, n * sizeof(rt_ray_isect)));
-  HIPCHECK(hipMalloc(reinterpret_cast<void **>(&d_rgba), n * 4 * sizeof(float)));
+  HIPCHECK(hipMalloc(reinterpret_cast<void **>(&d_frame), n * 4 * sizeof(float)));
+  HIPCHECK(hipMalloc(reinterpret_cast<void **>(&d_layer), n * 4 * sizeof(float)));
+  HIPCHECK(hipMalloc(&d_bgra, n * 4));
   HIPCHECK(hipMemcpy(d_cam, rays.data(), n * sizeof(rt_ray_isect), hipMemcpyHostToDevice));
 
+  // The frame stays on the device: pass 0 writes the opaque layer, every reflection pass writes its layer and
+  // rt_composite_layers blends it over the frame (in place); the last call also writes the 8-bit pixels, the only thing
+  // that is downloaded.
   const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-  std::vector<float> frame(n * 4, 0.f), layer(n * 4);
   auto t0 = std::chrono::steady_clock::now();
   void *src = d_cam, *dst = d_a;
   for (int pass = 0; pass <= bounces; ++pass) {
-    CHECK(rt_trace_pass(scene, src, dst, d_rgba, n, identity, pass == 0 ? 0u : 1u, nullptr));
-    HIPCHECK(hipDeviceSynchronize());
-    HIPCHECK(hipMemcpy(layer.data(), d_rgba, n * 4 * sizeof(float), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) {
-      float *f = &frame[4 * i];
-      const float *l = &layer[4 * i];
-      if (pass == 0) {
-        std::memcpy(f, l, 4 * sizeof(float));
-      } else {  // glBlendFunc(GL_SRC_ALPHA, GL_ONE_MINUS_DST_ALPHA)
-        const float sa = l[3], da = f[3];
-        for (int c = 0; c < 4; ++c) f[c] = l[c] * sa + f[c] * (1.f - da);
-      }
-    }
+    CHECK(rt_trace_pass(scene, src, dst, pass == 0 ? d_frame : d_layer, n, identity, pass == 0 ? 0u : 1u, nullptr));
+    const bool last = pass == bounces;
+    if (pass > 0) CHECK(rt_composite_layers(device, d_frame, d_layer, n, d_frame, last ? d_bgra : nullptr, nullptr));
+    else if (last) CHECK(rt_composite_layers(device, d_frame, nullptr, n, nullptr, d_bgra, nullptr));
     src = dst;
     dst = (dst == d_a) ? d_b : d_a;
   }
-  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  std::printf("%d pass(es) over %zu rays in %.3f ms (including layer download)\n", bounces + 1, n, ms);
-
   std::vector<uint8_t> bgra(n * 4);
-  for (size_t i = 0; i < n; ++i) {
-    auto q = [](float x) { return static_cast<uint8_t>(std::min(255.f, std::max(0.f, x * 255.f + 0.5f))); };
-    bgra[4 * i + 0] = q(frame[4 * i + 2]);
-    bgra[4 * i + 1] = q(frame[4 * i + 1]);
-    bgra[4 * i + 2] = q(frame[4 * i + 0]);
-    bgra[4 * i + 3] = 255;
-  }
+  HIPCHECK(hipMemcpy(bgra.data(), d_bgra, n * 4, hipMemcpyDeviceToHost));   // waits for the passes (null stream)
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  std::printf("%d pass(es) over %zu rays in %.3f ms (including the download of the 8-bit frame)\n", bounces + 1, n, ms);
+
   CHECK(rt_write_bmp32(out.c_str(), bgra.data(), W, H));
   std::printf("wrote %s\n", out.c_str());
 
-  (void)hipFree(d_cam); (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_rgba);
+  (void)hipFree(d_cam); (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_frame); (void)hipFree(d_layer); (void)hipFree(d_bgra);
   rt_scene_destroy(scene);
   rt_bvh_destroy(bvh);
   rt_mesh_destroy(mesh);
