@@ -155,7 +155,6 @@ struct rt_scene {
   mutable int fb_cur = 0, fb_newest = 0;                    // set the launches record into; set of the sort enqueued last
   int model_width = 0;                                      // rt_scene_wave_model only: 8 = price an eight-wide collapse of the tree
   int side_stream = 1;                                      // 0: the order-building kernels run on the launch's own stream, behind the trace kernel
-  int side_priority = 0;                                    // 1: the order-building side stream is created at the highest stream priority
   int feedback_period = 8;                                  // every this-many launches one records its costs and a sort follows it
   mutable hipStream_t side = nullptr;                       // the order-building kernel runs here, beside the next trace
   mutable hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_sort[2] = {nullptr, nullptr};
@@ -376,18 +375,12 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
         }
       }
       if (!s->side && s->side_stream) {
-        // The side stream must be NON-BLOCKING.  A stream created with default flags (which is what
-        // hipStreamCreateWithPriority(&q, 0, prio) gives) synchronises implicitly with the legacy null stream: a trace launch
-        // of a null-stream caller then waits for everything the side stream holds, and the side stream's head waits for that
-        // launch's stop event -- a cycle that stops both for good.  hipStreamNonBlocking takes the stream out of the null
-        // stream's implicit barrier, with or without a priority ("side_priority").
-        if (s->side_priority) {
-          int least = 0, greatest = 0;
-          RT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-          RT_HIP(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, greatest));
-        } else {
-          RT_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
-        }
+        // The side stream is NON-BLOCKING and of DEFAULT priority.  A stream created with default flags synchronises
+        // implicitly with the legacy null stream, so a null-stream caller's trace launch would wait for everything the side
+        // stream holds while the side stream's head waits for that launch's stop event.  A stream of raised priority is not
+        // offered either: its head is a wait for a signal that only a lower-priority queue's kernel can send, and a
+        // null-stream caller was seen to stop for good with it (non-blocking flag set) in one run of two.
+        RT_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
         unsigned side_flags = 0;
         RT_HIP(hipStreamGetFlags(s->side, &side_flags));
         if (!(side_flags & hipStreamNonBlocking)) return Fail(RT_ERR_DEVICE, "internal: the order-building stream is not non-blocking");
@@ -852,16 +845,6 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "feedback_period") {
     if (value < 1 || value > 1024) return Fail(RT_ERR_INVALID, "feedback_period must be in 1..1024");
     s->feedback_period = value;
-  } else if (k == "side_priority") {
-    if (value < 0 || value > 1) return Fail(RT_ERR_INVALID, "side_priority must be 0 or 1");
-    if (s->side && value != s->side_priority) {   // the stream is made on first use: drop it so that the next launch makes the other kind
-      DeviceGuard guard(s->device);
-      int rc = ResetFeedback(s);
-      if (rc != RT_OK) return rc;
-      (void)hipStreamDestroy(s->side);
-      s->side = nullptr;
-    }
-    s->side_priority = value;
   } else if (k == "model_width") {
     if (value != 0 && value != 8) return Fail(RT_ERR_INVALID, "model_width must be 0 (as traced) or 8");
     s->model_width = value;
