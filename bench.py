@@ -37,6 +37,7 @@ import argparse
 import contextlib
 import json
 import os
+import threading
 import time
 import types
 
@@ -105,6 +106,9 @@ def parse():
                          "the same primary rays are generated inside the kernel (rt_trace_primary), no ray array is read")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 flow on one GPU)")
+    ap.add_argument("--extras-deadline", type=float, default=150.0, metavar="SECONDS",
+                    help="tiles4k with N > 1: the extra measurements beside the headline (re-deal, one-GPU frame and framebuffer check, "
+                         "the other gathered record, frame-parallel figure) get this long; then rank 0 prints the line with what it has")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--share-of", type=int, default=0, metavar="R",
                     help="rehearsal on one GPU (tiles4k, --gpus 1, with --no-cpu-baseline): trace, scatter and time only the "
@@ -367,6 +371,18 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         if int(ok.item()) == 0 and comm is not None:
             comm.close()
             comm = None
+        if comm is not None:
+            # every RCCL call the exchange uses, once, with the result looked at on the host (rt_comm_check; a collective,
+            # so it runs only once every rank holds a communicator)
+            try:
+                comm.check()
+            except rt.RtError as e:
+                extra["rt_comm_check_failed"] = str(e)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                comm.close()
+                comm = None
 
     def sum_over_ranks(values):
         """In place, float64 host array: the sum over the job's ranks (RCCL through the library; gloo in the rehearsal)."""
@@ -629,14 +645,6 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         extra["squares_redealt_every_frames"] = a.redeal
     else:
         ms_per_step = run(sh, a.steps, a.warmup)
-    # what the host spends enqueueing a step (nothing waited for): the floor of a step however fast the GPU is
-    torch.cuda.synchronize()
-    c0 = time.perf_counter()
-    for _ in range(50):
-        sh.step()
-    extra["host_enqueue_us_per_step"] = round((time.perf_counter() - c0) / 50 * 1e6, 1)
-    sh.flush()
-    torch.cuda.synchronize()
     n_total = n_local
     if dist:
         nn = torch.tensor([n_local], dtype=torch.float64, device=red_dev)
@@ -664,6 +672,102 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
                          ("rt_gather_scatter, one rank" if world == 1 else
                           ("gloo through host memory (rehearsal)" if a.backend == "gloo" else "torch.distributed batch_isend_irecv (the library's communicator "
                            "could not be made)") + " + rt_gather_scatter for the scatter"))
+    # ---- everything the JSON line needs is measured; what follows are extras beside it.  On several GPUs they run under a
+    # deadline: should one of them stall (they exercise paths no one-GPU run can), rank 0 still prints the line with the extras
+    # it has and every rank leaves.
+    base_line = {}
+    emitted = threading.Lock()
+
+    def emit(cut_short=None):
+        if not emitted.acquire(blocking=False):
+            return
+        if rank == 0:
+            out = dict(base_line)
+            out.update(extra)
+            if cut_short is not None:
+                out["extras_cut_short_after_s"] = cut_short
+            print(json.dumps(out), flush=True)
+
+    def expired():
+        emit(a.extras_deadline)
+        os._exit(0)
+    if rank == 0:
+        n_count = min(n_local, 1 << 24)
+        cnt = scene.count_fetches_device(rays_d.data_ptr(), n_count)
+        n_node, n_tri = cnt["nodes"] / cnt["rays"], cnt["tris"] / cnt["rays"]
+        out_b = 16
+        stream_b = 64 + out_b
+        trav_b = n_node * info["node4_bytes"] + n_tri * info["tri_bytes"]
+        secs = trace_ms * 1e-3          # the roofline figures are the trace kernel's, not the exchange's
+        hbm = {"achieved": round(stream_b * n_local / secs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "what": f"compulsory streams of this rank's trace launch: 64 B ray in + {out_b} B out"}
+        hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBS, 4)
+        roofline = {"bound": "hbm", "achieved": hbm["achieved"], "peak": hbm["peak"], "unit": hbm["unit"], "frac": hbm["frac"], "traffic": None,
+                    "resources": {"hbm": hbm}, "kernel": "ClosestHitKernel", "kernel_ms": round(trace_ms, 4),
+                    "algorithmic": {"bytes_per_ray": round(stream_b + trav_b, 1), "stream_bytes_per_ray": stream_b,
+                                    "node_records_per_ray": round(n_node, 3), "tri_records_per_ray": round(n_tri, 3),
+                                    "node_bytes": info["node4_bytes"], "tri_bytes": info["tri_bytes"],
+                                    "hit_fraction": round(cnt["rays_hit"] / cnt["rays"], 4)}}
+        cpu = cpu_bvh = None
+        if world == 1 and R == 1 and not a.no_cpu_baseline and a.gather in ("hits8", "hits16"):
+            import oracle  # the CPU checker, used here only as the timed baseline
+            for fb in sh.fbs:
+                fb.fill_(-1)            # wiped first: the check below must see THIS step's gather and scatter
+            torch.cuda.synchronize()
+            sh.start()
+            sh.step()
+            sh.flush()
+            torch.cuda.synchronize()
+            fb = sh.state.last.cpu().numpy()
+            threads = oracle.default_threads()
+            sgr = a.cpu_stride
+            sel = (np.arange(0, H, sgr)[:, None] * W + np.arange(0, W, sgr)[None, :]).reshape(-1)
+            c0 = time.perf_counter()
+            oid, ot, _, _ = oracle.closest_hit(mesh.verts, mesh.faces, full_h[sel], threads=threads)
+            cdt = time.perf_counter() - c0
+            hit = oid != rt.MISS_ID
+            gid, gt = fb[sel, 0].view(np.uint32), fb[sel, 1].view(np.float32)
+            cpu = {"value": round(len(sel) / cdt / 1e6, 6), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                   "sample": f"stride-{sgr} sub-grid of the {W}x{H} ray set ({len(sel)} rays x {len(mesh.faces)} triangles, brute force)",
+                   "seconds": round(cdt, 2), "id_mismatches_vs_gpu": int((gid != oid).sum()),
+                   "t_bit_mismatches_vs_gpu": int((gt[hit].view(np.uint32) != ot[hit].view(np.uint32)).sum())}
+            c0 = time.perf_counter()
+            oid, ot, _, _ = oracle.closest_hit_bvh(mesh.verts, mesh.faces, bvh.nodes, full_h, threads=threads)
+            cdt = time.perf_counter() - c0
+            hit = oid != rt.MISS_ID
+            gid, gt = fb[:, 0].view(np.uint32), fb[:, 1].view(np.float32)
+            cpu_bvh = {"value": round(len(full_h) / cdt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                       "sample": f"all {len(full_h)} rays, closest hit through the same CentroidBVH tree (oracle tree walk), against the gathered framebuffer",
+                       "seconds": round(cdt, 2), "id_mismatches_vs_gpu": int((gid != oid).sum()),
+                       "t_bit_mismatches_vs_gpu": int((gt[hit].view(np.uint32) != ot[hit].view(np.uint32)).sum())}
+        line = {
+            "metric": "closest-hit Mrays/s", "value": round(mrays, 1), "unit": "Mrays/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{model} {W}x{H} primary rays, image squares sharded over {world} GPU(s), framebuffer gathered to rank 0",
+                       "name": "tiles4k", "rays_per_gpu": n_local, "rays_total": n_total, "triangles": len(mesh.faces), "loader": "tolerant",
+                       "bvh": a.bvh, "bvh_width": 4, "nodes": info["nodes4"], "hit_record": WHAT[a.gather],
+                       "rays": "RayIntersection table resident in HBM",
+                       "parallelism": f"{world} x one process per GPU, cost-balanced image squares (rt_shard_plan) + RCCL gather into rank 0 and "
+                                      f"device scatter (rt_gather_scatter), {sh.NB} frame(s) in flight"},
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_bvh": cpu_bvh,
+        }
+        base_line.update(line)
+    deadline = None
+    if world > 1 and a.extras_deadline > 0:
+        if dist:
+            dist.barrier()
+        deadline = threading.Timer(a.extras_deadline, expired)
+        deadline.daemon = True
+        deadline.start()
+    # what the host spends enqueueing a step (nothing waited for): the floor of a step however fast the GPU is
+    torch.cuda.synchronize()
+    c0 = time.perf_counter()
+    for _ in range(50):
+        sh.step()
+    extra["host_enqueue_us_per_step"] = round((time.perf_counter() - c0) / 50 * 1e6, 1)
+    sh.flush()
+    torch.cuda.synchronize()
     if sh.frames_in_flight >= 1:
         ms_1 = run(solo, sub, 2)
         extra["same_steps_one_frame_at_a_time"] = {"ms_per_step": round(ms_1, 4), "value": round(n_total / (ms_1 * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
@@ -739,69 +843,9 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         scene.set_param("image_width", hint)
         del rays_f, hits_f
 
-    if rank == 0:
-        n_count = min(n_local, 1 << 24)
-        cnt = scene.count_fetches_device(rays_d.data_ptr(), n_count)
-        n_node, n_tri = cnt["nodes"] / cnt["rays"], cnt["tris"] / cnt["rays"]
-        out_b = 16
-        stream_b = 64 + out_b
-        trav_b = n_node * info["node4_bytes"] + n_tri * info["tri_bytes"]
-        secs = trace_ms * 1e-3          # the roofline figures are the trace kernel's, not the exchange's
-        hbm = {"achieved": round(stream_b * n_local / secs / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "what": f"compulsory streams of this rank's trace launch: 64 B ray in + {out_b} B out"}
-        hbm["frac"] = round(hbm["achieved"] / HBM_PEAK_GBS, 4)
-        roofline = {"bound": "hbm", "achieved": hbm["achieved"], "peak": hbm["peak"], "unit": hbm["unit"], "frac": hbm["frac"], "traffic": None,
-                    "resources": {"hbm": hbm}, "kernel": "ClosestHitKernel", "kernel_ms": round(trace_ms, 4),
-                    "algorithmic": {"bytes_per_ray": round(stream_b + trav_b, 1), "stream_bytes_per_ray": stream_b,
-                                    "node_records_per_ray": round(n_node, 3), "tri_records_per_ray": round(n_tri, 3),
-                                    "node_bytes": info["node4_bytes"], "tri_bytes": info["tri_bytes"],
-                                    "hit_fraction": round(cnt["rays_hit"] / cnt["rays"], 4)}}
-        cpu = cpu_bvh = None
-        if world == 1 and R == 1 and not a.no_cpu_baseline and a.gather in ("hits8", "hits16"):
-            import oracle  # the CPU checker, used here only as the timed baseline
-            for fb in sh.fbs:
-                fb.fill_(-1)            # wiped first: the check below must see THIS step's gather and scatter
-            torch.cuda.synchronize()
-            sh.start()
-            sh.step()
-            sh.flush()
-            torch.cuda.synchronize()
-            fb = sh.state.last.cpu().numpy()
-            threads = oracle.default_threads()
-            sgr = a.cpu_stride
-            sel = (np.arange(0, H, sgr)[:, None] * W + np.arange(0, W, sgr)[None, :]).reshape(-1)
-            c0 = time.perf_counter()
-            oid, ot, _, _ = oracle.closest_hit(mesh.verts, mesh.faces, full_h[sel], threads=threads)
-            cdt = time.perf_counter() - c0
-            hit = oid != rt.MISS_ID
-            gid, gt = fb[sel, 0].view(np.uint32), fb[sel, 1].view(np.float32)
-            cpu = {"value": round(len(sel) / cdt / 1e6, 6), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                   "sample": f"stride-{sgr} sub-grid of the {W}x{H} ray set ({len(sel)} rays x {len(mesh.faces)} triangles, brute force)",
-                   "seconds": round(cdt, 2), "id_mismatches_vs_gpu": int((gid != oid).sum()),
-                   "t_bit_mismatches_vs_gpu": int((gt[hit].view(np.uint32) != ot[hit].view(np.uint32)).sum())}
-            c0 = time.perf_counter()
-            oid, ot, _, _ = oracle.closest_hit_bvh(mesh.verts, mesh.faces, bvh.nodes, full_h, threads=threads)
-            cdt = time.perf_counter() - c0
-            hit = oid != rt.MISS_ID
-            gid, gt = fb[:, 0].view(np.uint32), fb[:, 1].view(np.float32)
-            cpu_bvh = {"value": round(len(full_h) / cdt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                       "sample": f"all {len(full_h)} rays, closest hit through the same CentroidBVH tree (oracle tree walk), against the gathered framebuffer",
-                       "seconds": round(cdt, 2), "id_mismatches_vs_gpu": int((gid != oid).sum()),
-                       "t_bit_mismatches_vs_gpu": int((gt[hit].view(np.uint32) != ot[hit].view(np.uint32)).sum())}
-        line = {
-            "metric": "closest-hit Mrays/s", "value": round(mrays, 1), "unit": "Mrays/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{model} {W}x{H} primary rays, image squares sharded over {world} GPU(s), framebuffer gathered to rank 0",
-                       "name": "tiles4k", "rays_per_gpu": n_local, "rays_total": n_total, "triangles": len(mesh.faces), "loader": "tolerant",
-                       "bvh": a.bvh, "bvh_width": 4, "nodes": info["nodes4"], "hit_record": WHAT[a.gather],
-                       "rays": "RayIntersection table resident in HBM",
-                       "parallelism": f"{world} x one process per GPU, cost-balanced image squares (rt_shard_plan) + RCCL gather into rank 0 and "
-                                      f"device scatter (rt_gather_scatter), {sh.NB} frame(s) in flight"},
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_bvh": cpu_bvh,
-        }
-        line.update(extra)
-        print(json.dumps(line), flush=True)
+    if deadline is not None:
+        deadline.cancel()
+    emit()
     if dist:
         dist.barrier()
     if comm is not None:

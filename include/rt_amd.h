@@ -334,8 +334,16 @@ int rt_comm_create(const uint8_t id[RT_COMM_ID_BYTES], int nranks, int rank, int
 void rt_comm_destroy(void *comm);
 
 /* values[i] := sum over the ranks of values[i] (host memory; ncclAllReduce on a stream of its own, waited for).  A collective:
- * every rank calls it with the same n.  nranks = 1 leaves the values alone and needs no communicator. */
+ * every rank calls it with the same n.  nranks = 1 needs no communicator (the values are left alone; with one, the call
+ * still goes through RCCL). */
 int rt_comm_sum_f64(void *comm, int nranks, int device, double *values, size_t n);
+
+/* Health check of a communicator, a collective (every rank calls it): each rank sends 4 KB that name it to the next rank
+ * and receives the previous rank's in one grouped ncclSend/ncclRecv (one rank exchanges with itself), the words are
+ * compared on the host, and {1, rank} is summed over the ranks with rt_comm_sum_f64.  Exercises every RCCL call the
+ * exchange step uses; a job runs it once after rt_comm_create, before the first frame.  No counterpart in the reference
+ * (which renders on one device). */
+int rt_comm_check(void *comm, int nranks, int rank, int device);
 
 /* The exchange step of a sharded frame, enqueued on `stream` of every rank (call it on all ranks, like a collective):
  * every rank but `root` sends its records (mine_dev, rank_first_record[rank + 1] - rank_first_record[rank] of them,

@@ -112,6 +112,7 @@ def _load():
         "rt_comm_unique_id": (i32, [vp]),
         "rt_comm_create": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
         "rt_comm_destroy": (None, [vp]),
+        "rt_comm_check": (i32, [vp, i32, i32, i32]),
         "rt_gather_scatter": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, sz, vp, vp, sz, i32, i32, i32, vp, vp]),
         "rt_scene_wave_timeline": (i32, [vp, vp, sz, vp, sz]),
         "rt_scene_wave_model": (i32, [vp, vp, sz, u32, u32, sz, i32, C.POINTER(u64)]),
@@ -466,6 +467,10 @@ class Comm:
         assert values.dtype == np.float64 and values.flags.c_contiguous
         _check(lib.rt_comm_sum_f64(self._h, self.nranks, self.device, _ptr(values), values.size))
         return values
+
+    def check(self):
+        """A real exchange around the ring of ranks and a sum over them (rt_comm_check; a collective)."""
+        _check(lib.rt_comm_check(self._h, self.nranks, self.rank, self.device))
 
     @staticmethod
     def unique_id():

@@ -310,7 +310,7 @@ void rt_comm_destroy(void *comm)
 int rt_comm_sum_f64(void *comm, int nranks, int device, double *values, size_t n)
 {
   if (nranks <= 0 || (n && !values)) return RtFail(RT_ERR_INVALID, "bad arguments");
-  if (nranks == 1 || n == 0) return RT_OK;
+  if (n == 0 || (nranks == 1 && !comm)) return RT_OK;   // one rank WITH a communicator still goes through RCCL (rt_comm_check relies on it)
   if (!comm) return RtFail(RT_ERR_INVALID, "a communicator is needed for more than one rank");
   Rccl *r = LoadRccl();
   if (!r->why.empty()) return RtFail(RT_ERR_DEVICE, r->why);
@@ -330,6 +330,53 @@ int rt_comm_sum_f64(void *comm, int nranks, int device, double *values, size_t n
   (void)hipFree(d);
   if (e != 0) return FailNccl(r, e, "ncclAllReduce");
   if (he != hipSuccess) return RtFail(RT_ERR_DEVICE, std::string("sum over ranks: ") + hipGetErrorString(he));
+  return RT_OK;
+}
+
+int rt_comm_check(void *comm, int nranks, int rank, int device)
+{
+  if (!comm || nranks <= 0 || rank < 0 || rank >= nranks) return RtFail(RT_ERR_INVALID, "bad communicator arguments");
+  Rccl *r = LoadRccl();
+  if (!r->why.empty()) return RtFail(RT_ERR_DEVICE, r->why);
+  DeviceScope scope(device);
+  if (!scope.ok) return RtFail(RT_ERR_DEVICE, "hipSetDevice failed");
+  // Every rank sends kWords words that name it to the next rank and receives the previous rank's (one grouped call, the
+  // same calls rt_gather_scatter makes; one rank exchanges with itself), then the ranks sum {1, rank} as doubles.
+  constexpr size_t kWords = 1024;
+  const int next = (rank + 1) % nranks, prev = (rank + nranks - 1) % nranks;
+  std::vector<uint32_t> out(kWords), in(kWords, 0u);
+  for (size_t i = 0; i < kWords; ++i) out[i] = 0x9E3779B9u * static_cast<uint32_t>(rank + 1) + static_cast<uint32_t>(i);
+  uint32_t *d = nullptr;
+  hipStream_t q = nullptr;
+  hipError_t he = hipMalloc(reinterpret_cast<void **>(&d), 2 * kWords * sizeof(uint32_t));
+  if (he != hipSuccess) return RtFail(RT_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(he));
+  int e = 0, e2 = 0;
+  he = hipStreamCreateWithFlags(&q, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipMemcpyAsync(d, out.data(), kWords * sizeof(uint32_t), hipMemcpyHostToDevice, q);
+  if (he == hipSuccess) he = hipMemsetAsync(d + kWords, 0, kWords * sizeof(uint32_t), q);
+  if (he == hipSuccess) {
+    e = r->GroupStart();
+    if (e == 0) e = r->Send(d, kWords * sizeof(uint32_t), kNcclUint8, next, comm, q);
+    if (e == 0) e = r->Recv(d + kWords, kWords * sizeof(uint32_t), kNcclUint8, prev, comm, q);
+    e2 = r->GroupEnd();
+  }
+  if (he == hipSuccess && e == 0 && e2 == 0) he = hipMemcpyAsync(in.data(), d + kWords, kWords * sizeof(uint32_t), hipMemcpyDeviceToHost, q);
+  if (he == hipSuccess && e == 0 && e2 == 0) he = hipStreamSynchronize(q);
+  if (q) (void)hipStreamDestroy(q);
+  (void)hipFree(d);
+  if (e != 0) return FailNccl(r, e, "ncclSend/ncclRecv");
+  if (e2 != 0) return FailNccl(r, e2, "ncclGroupEnd");
+  if (he != hipSuccess) return RtFail(RT_ERR_DEVICE, std::string("communicator check: ") + hipGetErrorString(he));
+  for (size_t i = 0; i < kWords; ++i)
+    if (in[i] != 0x9E3779B9u * static_cast<uint32_t>(prev + 1) + static_cast<uint32_t>(i))
+      return RtFail(RT_ERR_DEVICE, "communicator check: the words received from rank " + std::to_string(prev) + " are not the ones it sent");
+  double sums[2] = {1.0, static_cast<double>(rank)};
+  {
+    int rc = rt_comm_sum_f64(comm, nranks, device, sums, 2);
+    if (rc != RT_OK) return rc;
+  }
+  if (sums[0] != static_cast<double>(nranks) || sums[1] != 0.5 * nranks * (nranks - 1.0))
+    return RtFail(RT_ERR_DEVICE, "communicator check: the sum over the ranks is wrong");
   return RT_OK;
 }
 

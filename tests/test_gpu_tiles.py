@@ -144,6 +144,7 @@ def test_gather_scatter_entry_point_with_a_one_rank_communicator_and_logical_ran
     scene.set_param("width", 4)
     comm = rt.Comm(rt.Comm.unique_id(), 1, 0, gpu)
     try:
+        comm.check()     # grouped ncclSend/ncclRecv (with itself) and the host comparison: the run-time RCCL binding works
         rays_d = torch.from_numpy(rays).cuda()
         want = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
         scene.set_param("image_width", W)
