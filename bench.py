@@ -23,11 +23,14 @@ Workloads:
 The scene is built the way the reference builds it: tolerant OBJ load, core/CentroidBVH build with the
 centroid-index repair (--bvh fixed).  --bvh sah swaps in the library's surface-area builder.
 
-Rank 0 prints ONE JSON line.  `roofline` carries one fraction per resource (hbm: compulsory ray/hit stream
-bytes against the 8 TB/s HBM3E peak; l2: L1-miss requests against the request rate a gather microbenchmark
-reaches on this chip; valu: vector instructions x their 2-cycle minimum issue time against all SIMD cycles);
-`frac` is the largest and `bound` names it.  Counter-derived inputs come from committed rocprofv3 passes
-(profiles/rNN/pmc_table.json) and are divided by the launch duration measured live with HIP events.
+Rank 0 prints ONE JSON line.  `roofline` is the byte roofline of the trace kernel: `achieved` = the bytes that have to
+cross HBM per launch (the ray and hit streams) over the launch time measured live with HIP events, `peak` = the 8 TB/s
+HBM3E peak, `traffic` = the HBM-side bytes the PMC counters saw per launch.  Beside it: `algorithmic_bytes` (streams +
+every node and triangle record fetched, counted exactly by the instrumented kernel, held against the HBM and the L2
+peak: most of it is served by L1 and L2) and `resources`, one fraction per resource (hbm as above; l2: L1-miss requests
+against the request rate a gather microbenchmark reaches on this chip; valu: vector instructions x their 2-cycle minimum
+issue time against all SIMD cycles), the busiest named in `busiest_resource`.  Counter-derived inputs come from committed
+rocprofv3 passes (profiles/rNN/pmc_table.json), used only while the kernel sources still hash as they did then.
 `cpu_baseline` times the CPU oracle (brute force over all triangles, the reference's cpu_raycast loop) on a
 bounded sample.
 """
@@ -48,6 +51,7 @@ import raytrace_amd as rt
 from raytrace_amd import tiles as tl
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak
+L2_PEAK_GBS = 34500.0       # aggregate L2 bandwidth of the eight XCDs
 SIMDS = 256 * 4             # vector units on the chip
 CLOCK_HZ = 2.4e9            # peak engine clock: the denominator of the VALU fraction
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -1031,11 +1035,20 @@ def main():
                            "lane_utilisation": round(pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0), 4),
                            # diagnostic, not a roofline: waves' VALU-active time overlaps within a SIMD, so this can pass 1
                            "busy_counter_over_simd_cycles": round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / secs / (SIMDS * CLOCK_HZ), 4)}
-        bound = max(res, key=lambda k: res[k]["frac"])
+        busiest = max(res, key=lambda k: res[k]["frac"])
         ops = n_node * width * 24 + n_tri * 52     # lane operations the algorithm needs: 24 per box test, 52 per triangle test
+        alg_gbs = (stream_b + trav_b) * n_local / secs / 1e9
         roofline = {
-            "bound": bound, "achieved": res[bound]["achieved"], "peak": res[bound]["peak"], "unit": res[bound]["unit"],
-            "frac": res[bound]["frac"], "traffic": traffic, "traffic_unit": "GB per launch, HBM side (2 x FETCH_SIZE + WRITE_SIZE)",
+            # the byte roofline: the bytes that have to cross HBM (the ray and hit streams) against the HBM3E peak; the
+            # other resources' fractions are under "resources" and the busiest of them is named beside it
+            "bound": "hbm", "achieved": res["hbm"]["achieved"], "peak": res["hbm"]["peak"], "unit": res["hbm"]["unit"],
+            "frac": res["hbm"]["frac"], "traffic": traffic, "traffic_unit": "GB per launch, HBM side (2 x FETCH_SIZE + WRITE_SIZE)",
+            "busiest_resource": busiest, "busiest_resource_frac": res[busiest]["frac"],
+            # every algorithmic byte (streams + node and triangle records fetched) per launch over the launch time: most of it
+            # is served by L1 and L2, so it is held against the L2 peak as well as the HBM peak
+            "algorithmic_bytes": {"per_launch_GB": round((stream_b + trav_b) * n_local / 1e9, 4), "GBs": round(alg_gbs, 1),
+                                  "over_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4), "l2_peak_GBs": L2_PEAK_GBS,
+                                  "over_l2_peak": round(alg_gbs / L2_PEAK_GBS, 4)},
             "resources": res, "counters_from": pmc_src if pmc else None, "counters_key": key, "counters_head": counters_head,
             "kernel": "RefillHitKernel" if refill_on else "ClosestHitKernel", "kernel_ms": round(dev_ms, 4),
             # the algorithmic traversal figure, never compared with the HBM peak: most of it is served by L1/L2
