@@ -129,13 +129,18 @@ int rt_scene_records(const rt_scene *s, int which, void *out, size_t capacity, s
  *                    takes an 8x8 pixel tile.  0 = unstructured: each wave takes 64 consecutive records.
  *   "centre_first"   image mode, while no cost-sorted order exists (the first two launches of a shape, or "feedback"
  *                    0): 1 dispatches the tiles nearest the image centre first, 0 in row order.
- *   "feedback"       1 (default): launches record the traversal cost of each wave-sized work unit; small sort kernels on
- *                    a library-owned side stream turn that into a costliest-first dispatch order, which later
- *                    launches of the same shape (ray count, image width) on this scene use, from the launch
- *                    after next on.  A schedule only: every ray is traced on every launch.  Any change of shape starts over.
+ *   "feedback"       1 (default): launches record the traversal cost of each wave-sized work unit; small sort kernels
+ *                    turn that into a costliest-first dispatch order, which later launches of the same shape (ray
+ *                    count, image width) on this scene use.  A schedule only: every ray is traced on every launch.
+ *                    Any change of shape starts over.
  *   "feedback_period" 1..1024 (default 8, with "feedback"): every this-many launches one records its costs and a
- *                    sort follows it; the launches between follow the newest finished order unchanged (each sort
- *                    costs the stream that traces about 6 us).  1 = every launch.
+ *                    sort follows it; the launches between follow the newest finished order unchanged (a sort costs
+ *                    the stream that traces about 13 us at 1080p: two small launches).  1 = every launch.
+ *   "side_stream"    0 (default): the sort kernels run on the launch's own stream, behind the launch that recorded the
+ *                    costs; the next launch already follows the new order.  1: on a library-owned non-blocking stream of
+ *                    default priority, beside the next launch (ordered by events; the order is used from the launch
+ *                    after next on).  Measured slower for one stream of launches (every launch starts ~5 us later with
+ *                    the second queue in play, more than the sort costs); offered for callers who time it otherwise.
  *   "feedback_radius" 0..3, "feedback_share" 0..128 (with "feedback"): a unit's measured cost also counts, scaled
  *                    by share/128, for the units within `radius` of it (tiles in both image directions), so
  *                    that the order still starts the right tiles first when the camera moved between the
@@ -146,10 +151,14 @@ int rt_scene_records(const rt_scene *s, int which, void *out, size_t capacity, s
  *                    rays, while the other lanes carry on.  For incoherent rays (AO-style: +34 % with 64-byte
  *                    records, +50 % with 16-byte hits at 40); coherent rays lose their shared paths with it (a
  *                    1080p primary table without the image hint runs 2.4x slower), hence off unless asked for.
- *   "split_units"    0..65536 (default 32, with "feedback"): a launch ends with its longest wave, and a wave is as
+ *   "split_units"    0..65536 (default 128, with "feedback"): a launch ends with its longest wave, and a wave is as
  *                    long as the traversal steps its rays need between them; this many units at the head of the
  *                    costliest-first order are traced by four waves each (4x4 pixels or 16 records per wave) instead
  *                    of one.  Capped at the launch's unit count; 0 = never.
+ *   "split_coop"     1 (default): those quarter waves work four lanes per ray -- one child box of the ray's node or one
+ *                    triangle of its leaf per lane, the quad agreeing on the nearest child / closest hit -- on the
+ *                    four-wide quantized layout, when the tree's worst-case stack fits the LDS columns of a quad.
+ *                    0: one ray per lane, 16 lanes busy.
  *   "leaf_pct"       1..100: a wave switches from node steps to leaf steps once this share of its busy lanes
  *                    holds a leaf; 100 = descend until every lane does.
  *   "block_threads"  64 (default), 128 or 256.
@@ -361,6 +370,11 @@ int rt_gather_scatter(void *comm, int rank, int nranks, int root, int device, co
  * 64 rays (or per 8x8 tile with the image hint), records[4*w..4*w+3] = {start, end in 100 MHz ticks,
  * HW_ID register, XCC_ID register}.  capacity is in uint64 elements. */
 int rt_scene_wave_timeline(const rt_scene *s, const void *rays_dev, size_t n, uint64_t *records, size_t capacity);
+
+/* Test hook: the dispatch order the cost-feedback schedule builds from a table of per-unit costs (host arrays): units by
+ * cost bin (cost / 8, capped at 31), costliest bin first, index order inside a bin.  costs_after (nullable) receives the
+ * cost table as the build leaves it (all zero). */
+int rt_debug_build_order(int device, const uint32_t *unit_costs, size_t nunits, uint32_t *order_out, uint32_t *costs_after);
 
 /* Test hook: runs the kernel's triangle test on n independent (triangle, ray) pairs
  * (host arrays: tri = 3 rt_vec3 per pair) and returns hit flag, t and (u,v) per pair. */

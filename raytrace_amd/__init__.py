@@ -113,6 +113,7 @@ def _load():
         "rt_comm_create": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
         "rt_comm_destroy": (None, [vp]),
         "rt_comm_check": (i32, [vp, i32, i32, i32]),
+        "rt_debug_build_order": (i32, [i32, vp, sz, vp, vp]),
         "rt_gather_scatter": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, sz, vp, vp, sz, i32, i32, i32, vp, vp]),
         "rt_scene_wave_timeline": (i32, [vp, vp, sz, vp, sz]),
         "rt_scene_wave_model": (i32, [vp, vp, sz, u32, u32, sz, i32, C.POINTER(u64)]),

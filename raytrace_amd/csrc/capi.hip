@@ -150,11 +150,12 @@ struct rt_scene {
   mutable uint32_t fb_ntasks = 0, fb_n = 0, fb_img_w = 0;  // shape the feedback buffers describe
   mutable bool fb_sorted[2] = {false, false};               // d_fb_order[k] holds (or will hold, after ev_sort[k]) an order
   mutable bool fb_pending[2] = {false, false};              // ... whose sort has not yet been seen to finish
+  mutable hipStream_t fb_sort_on[2] = {nullptr, nullptr};   // ... and the stream that sort was enqueued on
   mutable uint32_t fb_launch = 0;
   mutable uint32_t fb_since_sort = 0;                       // launches since the last one that recorded costs
   mutable int fb_cur = 0, fb_newest = 0;                    // set the launches record into; set of the sort enqueued last
   int model_width = 0;                                      // rt_scene_wave_model only: 8 = price an eight-wide collapse of the tree
-  int side_stream = 1;                                      // 0: the order-building kernels run on the launch's own stream, behind the trace kernel
+  int side_stream = 0;                                      // 0: the order-building kernel runs on the launch's own stream, behind the trace kernel; 1: on a side stream
   int feedback_period = 8;                                  // every this-many launches one records its costs and a sort follows it
   mutable hipStream_t side = nullptr;                       // the order-building kernel runs here, beside the next trace
   mutable hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_sort[2] = {nullptr, nullptr};
@@ -398,15 +399,17 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     for (int k = 0; k < 2; ++k)
       if (s->fb_pending[k] && hipEventQuery(s->ev_sort[k]) == hipSuccess) s->fb_pending[k] = false;
     (void)hipGetLastError();   // hipErrorNotReady from a query is not an error of this call
+    // a sort enqueued on the stream this launch goes to is finished, as far as this launch can tell, by stream order
+    auto pending = [&](int k) { return s->fb_pending[k] && !(s->side_stream == 0 && s->fb_sort_on[k] == stream); };
     bool waited = false;
-    if (sort_now && s->fb_pending[fb_slot]) {
+    if (sort_now && pending(fb_slot)) {
       // the sort that reads and zeroes this set's costs is still running: no launch may record into it yet
       RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[fb_slot], 0));
       waited = true;
     }
     int use = -1;
     for (int k : {s->fb_newest, 1 - s->fb_newest})
-      if (use < 0 && s->fb_sorted[k] && (!s->fb_pending[k] || (waited && k == fb_slot))) use = k;
+      if (use < 0 && s->fb_sorted[k] && (!pending(k) || (waited && k == fb_slot))) use = k;
     if (use < 0 && s->fb_sorted[s->fb_newest]) {
       use = s->fb_newest;
       RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[use], 0));
@@ -470,9 +473,13 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     if (s->side_stream) RT_HIP(hipStreamWaitEvent(sort_on, s->ev_main[fb_slot], 0));
     for (size_t k = 0; k < s->fb_left_used; ++k) RT_HIP(hipStreamWaitEvent(sort_on, s->fb_left[k], 0));
     s->fb_left_used = 0;
+    // sorts share their work space: one that may still be running on another stream comes first
+    const int other = 1 - fb_slot;
+    if (s->fb_pending[other] && s->fb_sort_on[other] != sort_on) RT_HIP(hipStreamWaitEvent(sort_on, s->ev_sort[other], 0));
     RT_HIP(rt::LaunchBuildOrder(s->d_fb_cost[fb_slot], a.ntasks, s->d_fb_bins, s->d_fb_order[fb_slot], sort_on));
     RT_HIP(hipEventRecord(s->ev_sort[fb_slot], sort_on));
     s->fb_sorted[fb_slot] = s->fb_pending[fb_slot] = true;
+    s->fb_sort_on[fb_slot] = sort_on;
     s->fb_newest = fb_slot;
     s->fb_cur = 1 - fb_slot;
     s->fb_since_sort = 0;
@@ -1439,6 +1446,29 @@ int rt_pack_bgra8(int device, const float *rgba_dev, size_t n, void *bgra_dev, v
   if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
   RT_HIP(rt::LaunchPackPixels(rgba_dev, static_cast<uint32_t>(n), bgra_dev, static_cast<hipStream_t>(stream)));
   return RT_OK;
+}
+
+int rt_debug_build_order(int device, const uint32_t *unit_costs, size_t nunits, uint32_t *order_out, uint32_t *costs_after)
+{
+  if (!unit_costs || !order_out || nunits == 0 || nunits > (size_t(1) << 24)) return Fail(RT_ERR_INVALID, "bad order arguments");
+  DeviceGuard guard(device);
+  if (!guard.ok) return Fail(RT_ERR_DEVICE, "hipSetDevice failed");
+  const uint32_t n = static_cast<uint32_t>(nunits);
+  const size_t padded = rt::OrderPaddedUnits(n);
+  uint32_t *d_cost = nullptr, *d_bins = nullptr, *d_order = nullptr;
+  int rc = Upload(&d_cost, nullptr, padded * sizeof(uint32_t));
+  if (rc == RT_OK) rc = Upload(&d_bins, nullptr, rt::OrderBinWords(n) * sizeof(uint32_t));
+  if (rc == RT_OK) rc = Upload(&d_order, nullptr, nunits * sizeof(uint32_t));
+  if (rc == RT_OK) {
+    hipError_t e = hipMemcpy(d_cost, unit_costs, nunits * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rt::LaunchBuildOrder(d_cost, n, d_bins, d_order, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(order_out, d_order, nunits * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && costs_after) e = hipMemcpy(costs_after, d_cost, nunits * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = FailHip(e, "order build");
+  }
+  (void)hipFree(d_cost); (void)hipFree(d_bins); (void)hipFree(d_order);
+  return rc;
 }
 
 int rt_debug_tri_batch(int device, const rt_vec3 *tri, const rt_ray *ray, size_t n, int32_t *hit, float *t, rt_vec2 *uv)

@@ -978,15 +978,19 @@ __global__ void __launch_bounds__(256, kRefillWavesPerSimd) RefillHitKernel(Kern
 }
 
 // Counting sort of work units by cost bin (cost / 8, capped), costliest bin first, ascending unit index inside a bin so
-// neighbouring units stay neighbours.  Three small launches of ONE-WAVE workgroups: the sort runs on a side stream beside a
-// trace launch that refills every wave slot the moment it frees, and a workgroup of several waves, which needs that many
-// slots of one CU free at the same time, waits there for most of that launch.  Every wave owns a chunk of kOrderChunk
+// neighbouring units stay neighbours.  Small launches of ONE-WAVE workgroups: the sort may run on a side stream beside a
+// trace launch that refills every wave slot the moment it frees, where a workgroup of several waves, which needs that many
+// slots of one CU free at the same time, would wait for most of that launch.  Every wave owns a chunk of kOrderChunk
 // consecutive keys (16 per lane, read as four 16-byte loads);
 //   1. OrderCountKernel    bins[bin][chunk] = keys of the chunk in that bin        (bin 0 = the costliest)
 //   2. OrderScanKernel     exclusive prefix sum over bins[][] in bin-major order  = where each (bin, chunk) run starts
 //   3. OrderScatterKernel  ranks the chunk's keys inside each bin in index order and writes the order; zeroes the keys
+// By default the sort runs on the trace launches' own stream, between two of them, where each launch costs its start-up
+// latency (6 + 10 + 7 us at 1080p for microseconds of work): up to kOrderDirectChunks chunks step 2 is folded into step 3
+// (every workgroup sums the rows of the raw count table itself), two launches instead of three.
 // unit_cost must be readable and writable up to OrderPaddedUnits(n) entries and is left all zero.
 constexpr uint32_t kOrderKeys = 16, kOrderChunk = 64u * kOrderKeys;
+constexpr uint32_t kOrderDirectChunks = 512;   // up to this many chunks (512 Ki units) the scan launch is folded into the scatter
 
 __device__ __forceinline__ uint32_t CostBin(uint32_t cost)
 {
@@ -1060,13 +1064,32 @@ __global__ void __launch_bounds__(64) OrderScanKernel(uint32_t *bins, uint32_t t
   }
 }
 
+// SCANNED: bins holds the scanned table (OrderScanKernel ran).  Otherwise it holds the raw counts and every workgroup works
+// out its own starts from them -- lane b sums row b (all chunks: the bin's total; the chunks before this one: the offset
+// inside the bin) and the totals are scanned across the lanes: redundant between workgroups, a few KB of L2 reads each, and
+// one launch fewer between two trace launches.
+template <bool SCANNED>
 __global__ void __launch_bounds__(64) OrderScatterKernel(uint32_t *unit_cost, uint32_t n, uint32_t nchunks, const uint32_t *bins,
                                                         uint32_t *order)
 {
   __shared__ uint32_t table[kFbBuckets * 64];   // [bin][lane]: counts, then next free position
   const uint32_t t = threadIdx.x, first = blockIdx.x * kOrderChunk + t * kOrderKeys;
   // where the chunk's run of bin t starts in the order (kFbBuckets <= 64)
-  const uint32_t start = t < static_cast<uint32_t>(kFbBuckets) ? bins[t * nchunks + blockIdx.x] : 0u;
+  uint32_t start = 0u;
+  if (SCANNED) {
+    if (t < static_cast<uint32_t>(kFbBuckets)) start = bins[t * nchunks + blockIdx.x];
+  } else {
+    uint32_t total = 0u, before = 0u;
+    if (t < static_cast<uint32_t>(kFbBuckets)) {
+      const uint32_t *row = bins + t * nchunks;
+      for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint32_t v = row[c];
+        total += v;
+        before += c < blockIdx.x ? v : 0u;
+      }
+    }
+    start = WaveScan(total, t) - total + before;   // lanes beyond the bins hold zeros
+  }
   uint32_t v[kOrderKeys];
   LoadOrderKeys(unit_cost, first, v);
   {
@@ -1231,8 +1254,12 @@ hipError_t LaunchBuildOrder(uint32_t *unit_cost, uint32_t nunits, uint32_t *bins
   const uint32_t nchunks = (nunits + kOrderChunk - 1u) / kOrderChunk;
   if (nchunks == 0) return hipSuccess;
   hipLaunchKernelGGL(OrderCountKernel, dim3(nchunks), dim3(64), 0, stream, unit_cost, nunits, nchunks, bins);
+  if (nchunks <= kOrderDirectChunks) {   // two launches: the scatter works its starts out from the raw counts
+    hipLaunchKernelGGL(OrderScatterKernel<false>, dim3(nchunks), dim3(64), 0, stream, unit_cost, nunits, nchunks, bins, order);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(OrderScanKernel, dim3(1), dim3(64), 0, stream, bins, nchunks * static_cast<uint32_t>(kFbBuckets));
-  hipLaunchKernelGGL(OrderScatterKernel, dim3(nchunks), dim3(64), 0, stream, unit_cost, nunits, nchunks, bins, order);
+  hipLaunchKernelGGL(OrderScatterKernel<true>, dim3(nchunks), dim3(64), 0, stream, unit_cost, nunits, nchunks, bins, order);
   return hipGetLastError();
 }
 

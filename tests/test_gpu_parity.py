@@ -799,3 +799,20 @@ def test_random_triangle_soups_at_many_scales(rt, oracle, gpu, seed):
                 for a, b in ((t, ot), (u, ou), (v, ov)):
                     assert np.array_equal(bits(a[h]), bits(b[h])), (mode, width, quant)
             scene.close()
+
+
+def test_dispatch_order_kernels_build_the_stable_bin_sort(rt, gpu):
+    """The costliest-first dispatch order (count, scan and scatter kernels) against numpy: units sorted by cost bin (cost / 8
+    capped at 31, costliest first), index order inside a bin -- a permutation of all units, and the cost table is left zeroed.
+    Sizes around the kernels' chunking (1024 keys per chunk, 2048 bin counters per scan tile) and the benchmark shapes
+    (32 400 units at 1080p, 129 600 at 4K)."""
+    rng = np.random.default_rng(11)
+    for n in (1, 63, 1024, 4096, 4097, 32400, 129600, 300000, 700000):   # the last one takes the separate scan launch
+        costs = np.where(rng.random(n) < 0.5, rng.integers(0, 8, n), rng.integers(0, 400, n)).astype(np.uint32)
+        bins = 31 - np.minimum(costs >> 3, 31)
+        want = np.argsort(bins, kind="stable").astype(np.uint32)
+        order = np.full(n, 0xFFFFFFFF, np.uint32)
+        after = np.full(n, 7, np.uint32)
+        rt._check(rt.lib.rt_debug_build_order(gpu, rt._ptr(costs), n, rt._ptr(order), rt._ptr(after)))
+        assert np.array_equal(order, want), n
+        assert not after.any(), n
