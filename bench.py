@@ -23,6 +23,10 @@ Workloads:
 The scene is built the way the reference builds it: tolerant OBJ load, core/CentroidBVH build with the
 centroid-index repair (--bvh fixed).  --bvh sah swaps in the library's surface-area builder.
 
+Before the W warm-up steps the card is brought to the clocks it holds under sustained load (--preheat-ms of dense
+matrix products, nothing of the hot path; see preheat()): the line names the duration (`gpu_preheat_ms`) and carries the same
+W + K steps timed on the idle card (`idle_gpu`).
+
 Rank 0 prints ONE JSON line.  `roofline` is the byte roofline of the trace kernel: `achieved` = the bytes that have to
 cross HBM per launch (the ray and hit streams) over the launch time measured live with HIP events, `peak` = the 8 TB/s
 HBM3E peak, `traffic` = the HBM-side bytes the PMC counters saw per launch.  Beside it: `algorithmic_bytes` (streams +
@@ -81,6 +85,10 @@ def parse():
                          "centroid indexing repaired (fixed, the default), or the surface-area build in the same node format (sah)")
     ap.add_argument("--out", default="full", choices=["full", "compact"], help="64-byte hit records or 16-byte {id,t,u,v}")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preheat-ms", type=float, default=600.0,
+                    help="before the warm-up steps: this long of unrelated GPU load (matrix products), so that the steps are timed at the "
+                         "clocks the card holds under sustained load; the same steps timed on the idle card are reported beside `value` "
+                         "(`idle_gpu`); 0 = none")
     ap.add_argument("--no-compare", action="store_true",
                     help="skip the extra timings beside the headline (surface-area tree, two streams, host-pointer call): profiling runs")
     ap.add_argument("--cpu-stride", type=int, default=4, help="sub-grid stride (both axes) of the CPU baseline sample")
@@ -145,6 +153,25 @@ def kernel_source_hash():
     for name in ("trace_kernels.hip", "trace_math.h"):
         h.update(open(os.path.join(ROOT, "raytrace_amd", "csrc", name), "rb").read())
     return h.hexdigest()[:16]
+
+
+def preheat(ms):
+    """Brings the GPU to the clocks it holds under sustained load before the warm-up steps: dense matrix products, nothing of
+    the hot path, for `ms` milliseconds.  The power management of the card takes about 0.3 s of load to get there (a 1080p
+    launch times 0.123 ms in its first 25 launches on an idle card and 0.115 ms after 0.4 s or more of any load,
+    tools/per_launch.py), far longer than a few warm-up launches last, and a render loop or a serving process runs at
+    the sustained state.  The line says how long it ran (`gpu_preheat_ms`) and carries the same K steps timed on the idle
+    card beside `value` (`idle_gpu`)."""
+    if ms <= 0:
+        return
+    m = torch.randn(4096, 4096, device="cuda")
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(4):
+            _ = m @ m
+        torch.cuda.synchronize()
+    del m, _
+    torch.cuda.synchronize()
 
 
 def timed(dist, steps, fn, finish=None):
@@ -228,6 +255,7 @@ def run_mirror5(a, local):
         for j in jobs:
             chain(j)
 
+    preheat(a.preheat_ms)
     for _ in range(a.warmup):
         step()
     wall, dev_ms = timed(None, a.steps, step)
@@ -317,7 +345,7 @@ def run_mirror5(a, local):
                    "bvh": a.bvh, "bvh_width": 4, "hit_record": "64B RayIntersection + 16B RGBA32F pixel",
                    "camera": "cube_mirror_test: reference pinhole from the +z side (rotation 2.6 rad about y); teapot: framed from -z",
                    "scenes": per_scene},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "gpu_preheat_ms": a.preheat_ms,
     }
     print(json.dumps(line), flush=True)
     for j in jobs:
@@ -618,6 +646,8 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         sh.state.fresh = False
         sh.step()
 
+    preheat(a.preheat_ms)      # the pipelines below are chosen, and the step timed, at the card's sustained clocks
+    extra["gpu_preheat_ms"] = a.preheat_ms
     if a.pipeline >= 0:
         sh = build(a.gather, a.pipeline, a.side_stream)
     else:
@@ -902,16 +932,15 @@ def main():
         sc = rt.Scene(mesh, tree, device=local, width=width)
         sc.set_param("width", width)
         sc.set_param("feedback", a.feedback)
+        if workload == "ao" and width == 4:
+            # incoherent rays: the kernel whose waves stream through the rays and refill their idle lanes (40 idle lanes trigger it)
+            sc.set_param("refill", 40)
         for kv in a.param:
             k, v = kv.split("=")
             sc.set_param(k, int(v))
         return sc
 
     scene = make_scene(bvh)
-    refill_on = False
-    if workload == "ao" and width == 4 and not any(kv.startswith("refill=") for kv in a.param):
-        # incoherent rays: the kernel whose waves stream through the rays and refill their idle lanes (40 idle lanes trigger it)
-        scene.set_param("refill", 40)
     refill_on = workload == "ao" and width == 4 and not any(kv == "refill=0" for kv in a.param)
     info = scene.info()
     box = bvh.root_box
@@ -967,6 +996,25 @@ def main():
         else:
             scene.intersect_async(rays_k.data_ptr(), n_local, None, hits_d.data_ptr(), stream)
 
+    idle_gpu = None
+    if a.preheat_ms > 0:
+        if world == 1:
+            # the same W warm-up and K timed steps on the card as this process found it, with a scene object of their own (so the
+            # steps timed for `value` below still start from a scene no launch has touched)
+            scene_run, scene = scene, make_scene(bvh)
+            if workload != "ao" and a.image_hint:
+                scene.set_param("image_width", W)
+            for _ in range(a.warmup):
+                step()
+            w_idle, _ = timed(None, a.steps, step)
+            scene.close()
+            scene = scene_run
+            step_no[0] = 0
+            idle_gpu = {"ms_per_step": round(w_idle * 1e3 / max(1, a.steps), 4), "value": round(n_local / (w_idle / max(1, a.steps)) / 1e6, 1),
+                        "unit": "Mrays/s", "what": "the same warm-up and timed steps before the card was brought to its sustained clocks"}
+        preheat(a.preheat_ms)
+        extra["gpu_preheat_ms"] = a.preheat_ms
+        extra["idle_gpu"] = idle_gpu
     for _ in range(a.warmup):
         step()
     wall, dev_ms = timed(dist, a.steps, step)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-launch durations of consecutive rt_intersect_async launches on one stream (an event between every two launches), to see
-what the launches that record costs and the order build beside the next launch cost: tools/per_launch.py [k=v ...]"""
+what the launches that record costs and the order build cost, and how the first launches of a scene differ from the later
+ones: tools/per_launch.py [warm=N] [n=N] [k=v ...]"""
 import os
 import sys
 
@@ -16,9 +17,17 @@ bvh = rt.BVH(mesh, "fixed")
 scene = rt.Scene(mesh, bvh, device=0, width=4)
 scene.set_param("width", 4)
 scene.set_param("image_width", W)
+WARM, N, SPIN_MS = 40, 96, 0
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
-    scene.set_param(k, int(v))
+    if k == "spin":
+        SPIN_MS = int(v)   # unrelated GPU work before the first launch (a large matrix product repeated for about this long)
+    elif k == "warm":
+        WARM = int(v)      # launches before the timed ones (bench.py --warmup)
+    elif k == "n":
+        N = int(v)
+    else:
+        scene.set_param(k, int(v))
 box = bvh.root_box
 tables = []
 for k in range(4):
@@ -27,14 +36,20 @@ for k in range(4):
     tables.append(torch.from_numpy(rt.primary_rays(W, H, o)).cuda())
 hits = torch.empty((W * H, 16), dtype=torch.float32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
-N = 96
-for i in range(40):
+if SPIN_MS:
+    import time
+    a_ = torch.randn(4096, 4096, device="cuda")
+    t_ = time.perf_counter()
+    while (time.perf_counter() - t_) * 1e3 < SPIN_MS:
+        b_ = a_ @ a_
+        torch.cuda.synchronize()
+for i in range(WARM):
     scene.intersect_async(tables[i % 4].data_ptr(), W * H, hits.data_ptr(), None, stream)
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
 ev[0].record()
 for i in range(N):
-    scene.intersect_async(tables[i % 4].data_ptr(), W * H, hits.data_ptr(), None, stream)
+    scene.intersect_async(tables[(WARM + i) % 4].data_ptr(), W * H, hits.data_ptr(), None, stream)
     ev[i + 1].record()
 torch.cuda.synchronize()
 d = np.array([ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(N)])
