@@ -643,9 +643,12 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
         dict(image_width=W, feedback=1, feedback_period=1, width=4),
         dict(image_width=W, feedback=1, feedback_period=2, block_threads=128),
         dict(image_width=0, feedback=1, feedback_period=3, width=4),
+        dict(image_width=W, feedback=1, feedback_period=1, width=4, side_stream=1),      # the order built on the library's side stream
+        dict(image_width=W, feedback=1, feedback_period=3, width=4, side_stream=1, split_units=64),
     ]
     defaults = dict(width=2, quantized=1, block_threads=64, image_width=0, leaf_pct=50, persistent=0, split_units=32, split_coop=1,
-                    feedback_period=4, persistent_waves=24, lds_stack=10, centre_first=1, feedback=0, feedback_radius=1, feedback_share=96)
+                    feedback_period=4, persistent_waves=24, lds_stack=10, centre_first=1, feedback=0, feedback_radius=1, feedback_share=96,
+                    side_stream=0)
     for cfg in settings:
         for k, v in {**defaults, **cfg}.items():
             scene.set_param(k, v)
