@@ -1004,7 +1004,7 @@ def main():
 
     idle_gpu = None
     if a.preheat_ms > 0:
-        if world == 1:
+        if world == 1 and not a.no_compare:
             # the same W warm-up and K timed steps on the card as this process found it, with a scene object of their own (so the
             # steps timed for `value` below still start from a scene no launch has touched)
             scene_run, scene = scene, make_scene(bvh)
