@@ -367,6 +367,13 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
     model, W, H = WORKLOADS["tiles4k"]
     assert a.tile % 8 == 0
     mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, model), "tolerant")
+    # The model ships no materials: every face names the all-zero sky material, and every pixel of the full trace step would be
+    # black.  One diffuse grey instead (same arithmetic per pixel), so that a pixel depends on where its ray hits and the
+    # comparison of the gathered framebuffer with the one-GPU frame can tell a misplaced square.
+    mats = mesh.materials.copy()
+    mats[:, 0:3] = 0.8
+    mats[:, 9] = 1.0
+    mesh = rt.Mesh.from_arrays(mesh.verts, mesh.faces, mesh.normals, mats)
     bvh = rt.BVH(mesh, a.bvh)
     def new_scene():
         sc = rt.Scene(mesh, bvh, device=local, width=4)
@@ -853,6 +860,7 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         torch.cuda.synchronize()
         if rank == 0:
             extra["framebuffer_equals_one_gpu"] = bool(torch.equal(sh.state.last, one_out))
+            extra["framebuffer_distinct_records"] = int(torch.unique(one_out, dim=0).shape[0])   # the comparison is not of one colour
             del one_out
         dist.barrier()
         # the same sharded frame with the 16-byte hit as the gathered record (twice the bytes on the links)
@@ -883,6 +891,41 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         scene.set_param("image_width", hint)
         del rays_f, hits_f
 
+    if R == world and (world == 1 or comm is not None):
+        # The same frame through the one-object-per-rank form of the step (rt_tiled_create / _redeal / _render): round-robin
+        # deal, one re-deal by measured cost, then one frame at a time on one stream, pixels as the gathered record.  Last of
+        # the extras: with N > 1 it is the first time this object meets more than one rank.
+        try:
+            tscene = new_scene()
+            tframe = rt.TiledFrame(tscene, comm, rank, world, W, H, a.tile, full_h, local, float(head[0]) if world > 1 else 0.0)
+            moved_t = tframe.redeal(cam)
+            fb_t = torch.full((W * H, 1), -1, dtype=torch.int32, device="cuda") if rank == 0 else None
+
+            def step_t():
+                tframe.render(cam, fb_t.data_ptr() if rank == 0 else None, null_stream)
+            for _ in range(max(3, a.warmup)):
+                step_t()
+            w_t, _ = timed(dist, sub, step_t)
+            tt = torch.tensor([w_t], dtype=torch.float64, device=red_dev)
+            if dist:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms_t = float(tt.item()) * 1e3 / sub
+            same = None
+            if rank == 0:
+                ref_t = torch.empty((W * H, 1), dtype=torch.int32, device="cuda")
+                scene.set_param("image_width", W)
+                scene.trace_pass_bgra8(full_d.data_ptr(), None, ref_t.data_ptr(), W * H, cam, 0, null_stream)
+                torch.cuda.synchronize()
+                scene.set_param("image_width", hint)
+                same = bool(torch.equal(fb_t, ref_t))
+                del ref_t
+            extra["rt_tiled_object"] = {"ms_per_step": round(ms_t, 4), "value": round(W * H / (ms_t * 1e-3) / 1e6, 1), "unit": "Mrays/s",
+                                        "frames_in_flight": 1, "squares_moved_by_its_redeal": moved_t, "rays_of_rank0": tframe.info()["rays"],
+                                        "framebuffer_equals_one_gpu": same}
+            tframe.close()
+            tscene.close()
+        except rt.RtError as e:
+            extra["rt_tiled_object"] = {"failed": str(e)}
     if deadline is not None:
         deadline.cancel()
     emit()

@@ -366,6 +366,28 @@ int rt_gather_scatter(void *comm, int rank, int nranks, int root, int device, co
                       const uint64_t *rank_first_record, size_t record_bytes, const uint32_t *tile_ids_dev, const uint32_t *tile_first_dev,
                       size_t ntiles, int tile, int width, int height, void *framebuffer_dev, void *stream);
 
+/* The calls above as one object per rank: the frame loop of render_client/img_main.cpp:447-498 (one enqueue on one
+ * device per frame) for a job of one process per GPU.  rt_tiled_create takes the frame's ray table (width x height records,
+ * host memory, copied: e.g. rt_primary_rays, the reference's camera table), deals the squares round-robin, uploads this
+ * rank's rays (its squares one after the other) and sets the scene's "image_width" to the squares' width -- give the object
+ * a scene of its own.  rt_tiled_render enqueues one frame on `stream` of every rank: the full trace step over this rank's
+ * rays (rt_trace_pass_bgra8, operation 0 with `cam`) and rt_gather_scatter; rank 0's framebuffer_dev (width x height 8-bit
+ * BGRA pixels, row-major; ignored on the other ranks) holds the frame when the stream gets there.  One frame at a time
+ * per object (frames on different streams would share its buffers): for frames in flight make one object, with a scene of
+ * its own, per slot.  rt_tiled_redeal is a collective that returns when done: every rank measures the traversal cost of
+ * its own squares under `cam`, the costs are summed over the ranks and the squares dealt again by cost
+ * (rt_shard_square_costs, rt_comm_sum_f64, rt_shard_plan; root_head_start as in rt_shard_plan, for rank 0); it waits for
+ * the device first and rebuilds the buffers; *squares_moved (nullable) = squares that changed rank.  What follows a
+ * moving camera: call it every so many frames.  rt_tiled_info: info[0..3] = {this rank's rays, its squares, squares of
+ * the frame, the image width its launches declare}.  nranks = 1 needs no communicator. */
+typedef struct rt_tiled rt_tiled;
+int rt_tiled_create(rt_scene *scene, void *comm, int rank, int nranks, int width, int height, int tile,
+                    const rt_ray_isect *frame_rays_host, int device, double root_head_start, rt_tiled **out);
+int rt_tiled_render(rt_tiled *t, const float cam[16], void *framebuffer_dev, void *stream);
+int rt_tiled_redeal(rt_tiled *t, const float cam[16], size_t *squares_moved);
+int rt_tiled_info(const rt_tiled *t, uint64_t info[4]);
+void rt_tiled_destroy(rt_tiled *t);
+
 /* Diagnostic: runs the instrumented kernel once over n device-resident rays and returns, per wave of
  * 64 rays (or per 8x8 tile with the image hint), records[4*w..4*w+3] = {start, end in 100 MHz ticks,
  * HW_ID register, XCC_ID register}.  capacity is in uint64 elements. */

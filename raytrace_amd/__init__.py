@@ -115,6 +115,11 @@ def _load():
         "rt_comm_check": (i32, [vp, i32, i32, i32]),
         "rt_debug_build_order": (i32, [i32, vp, sz, vp, vp]),
         "rt_gather_scatter": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, sz, vp, vp, sz, i32, i32, i32, vp, vp]),
+        "rt_tiled_create": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, C.c_double, C.POINTER(vp)]),
+        "rt_tiled_render": (i32, [vp, vp, vp, vp]),
+        "rt_tiled_redeal": (i32, [vp, vp, C.POINTER(sz)]),
+        "rt_tiled_info": (i32, [vp, C.POINTER(u64)]),
+        "rt_tiled_destroy": (None, [vp]),
         "rt_scene_wave_timeline": (i32, [vp, vp, sz, vp, sz]),
         "rt_scene_wave_model": (i32, [vp, vp, sz, u32, u32, sz, i32, C.POINTER(u64)]),
         "rt_debug_tri_batch": (i32, [i32, vp, vp, sz, vp, vp, vp]),
@@ -483,6 +488,45 @@ class Comm:
         h, self._h = getattr(self, "_h", None), None
         if h and lib is not None:
             lib.rt_comm_destroy(h)
+
+    def __del__(self):
+        self.close()
+
+
+class TiledFrame:
+    """rt_tiled_*: one rank's part of a frame rendered by `nranks` processes, one per GPU (the deal of the image squares, this
+    rank's rays, the exchange buffers).  `frame_rays` is the frame's whole ray table (W*H records); the scene gets the squares'
+    width as its "image_width" and should be used by this object only."""
+
+    def __init__(self, scene, comm, rank, nranks, width, height, tile, frame_rays, device, root_head_start=0.0):
+        assert frame_rays.dtype == np.float32 and frame_rays.flags.c_contiguous and frame_rays.shape == (width * height, RAY_FLOATS)
+        h = C.c_void_p()
+        _check(lib.rt_tiled_create(scene._h, comm._h if comm is not None else None, rank, nranks, width, height, tile, _ptr(frame_rays), device,
+                                   float(root_head_start), C.byref(h)))
+        self._h, self.scene, self.comm, self.rank, self.nranks = h, scene, comm, rank, nranks
+
+    def info(self):
+        v = (C.c_uint64 * 4)()
+        _check(lib.rt_tiled_info(self._h, v))
+        return {"rays": int(v[0]), "squares": int(v[1]), "squares_of_frame": int(v[2]), "image_width": int(v[3])}
+
+    def render(self, cam, framebuffer_ptr=None, stream=0):
+        """One frame, enqueued on `stream` (a collective: every rank calls it); rank 0's framebuffer receives W*H BGRA8 pixels."""
+        m = np.ascontiguousarray(cam, dtype=np.float32).reshape(16)
+        _check(lib.rt_tiled_render(self._h, _ptr(m), _ptr(framebuffer_ptr), C.c_void_p(stream) if stream else None))
+
+    def redeal(self, cam):
+        """Deals the squares again from the traversal costs measured under `cam` (a collective, synchronous); returns the number
+        of squares that changed rank."""
+        m = np.ascontiguousarray(cam, dtype=np.float32).reshape(16)
+        moved = C.c_size_t(0)
+        _check(lib.rt_tiled_redeal(self._h, _ptr(m), C.byref(moved)))
+        return int(moved.value)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:
+            lib.rt_tiled_destroy(h)
 
     def __del__(self):
         self.close()

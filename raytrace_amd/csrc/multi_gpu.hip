@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -130,6 +131,80 @@ __global__ void __launch_bounds__(256) CompositeKernel(const float4 *layer0, con
     bgra_out[i] = bl | (g << 8) | (r << 16) | 0xFF000000u;
   }
 }
+
+
+}  // namespace
+
+// One rank's part of a sharded frame, kept between frames: the deal, this rank's rays (its squares one after the other) and
+// the buffers of the exchange.
+struct rt_tiled {
+  rt_scene *scene = nullptr;
+  void *comm = nullptr;
+  int rank = 0, nranks = 1, device = 0, width = 0, height = 0, tile = 0, hint = 0;
+  double head = 0.0;                                   // the gathering rank's head start in a deal by cost
+  std::vector<rt_ray_isect> frame;                     // the whole frame's ray table (host copy; a re-deal picks from it)
+  std::vector<uint32_t> tile_order, my_first;          // the deal; where each of this rank's squares starts among its records
+  std::vector<uint64_t> first_tile, first_record;
+  std::vector<rt_ray_isect> rays;                      // host copy of this rank's rays
+  rt_ray_isect *d_rays = nullptr;
+  uint32_t *d_pixels = nullptr, *d_ids = nullptr, *d_first = nullptr;   // records (root: the gather buffer); root: all squares' tables
+  size_t n_local = 0;
+};
+
+namespace {
+
+void TiledFreeDevice(rt_tiled *t)
+{
+  if (t->d_rays) (void)hipFree(t->d_rays);
+  if (t->d_pixels) (void)hipFree(t->d_pixels);
+  if (t->d_ids) (void)hipFree(t->d_ids);
+  if (t->d_first) (void)hipFree(t->d_first);
+  t->d_rays = nullptr;
+  t->d_pixels = t->d_ids = t->d_first = nullptr;
+}
+
+template <class T>
+int TiledUpload(T **dst, const T *src, size_t count, size_t alloc_count)
+{
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), std::max<size_t>(1, alloc_count) * sizeof(T));
+  if (e == hipSuccess && src && count) e = hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return RtFail(e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, std::string("sharded frame buffers: ") + hipGetErrorString(e));
+  return RT_OK;
+}
+
+// Device buffers and tables for the deal the object holds (everything in flight must have finished).
+int TiledBuild(rt_tiled *t)
+{
+  DeviceScope scope(t->device);
+  if (!scope.ok) return RtFail(RT_ERR_DEVICE, "hipSetDevice failed");
+  TiledFreeDevice(t);
+  const uint32_t *my_ids = t->tile_order.data() + t->first_tile[t->rank];
+  const size_t nmy = t->first_tile[t->rank + 1] - t->first_tile[t->rank], ntiles = t->tile_order.size();
+  t->n_local = t->first_record[t->rank + 1] - t->first_record[t->rank];
+  std::vector<uint32_t> idx(t->n_local);
+  t->my_first.assign(nmy, 0u);
+  int rc = rt_shard_ray_indices(t->width, t->height, t->tile, my_ids, nmy, 0u, idx.data(), t->my_first.data());
+  if (rc != RT_OK) return rc;
+  t->rays.resize(t->n_local);
+  for (size_t k = 0; k < t->n_local; ++k) t->rays[k] = t->frame[idx[k]];
+  rc = TiledUpload(&t->d_rays, t->rays.data(), t->n_local, t->n_local);
+  if (rc != RT_OK) return rc;
+  if (t->rank == 0) {
+    std::vector<uint32_t> all_first(ntiles);
+    rc = rt_shard_ray_indices(t->width, t->height, t->tile, t->tile_order.data(), ntiles, 0u, nullptr, all_first.data());
+    if (rc == RT_OK) rc = TiledUpload(&t->d_ids, t->tile_order.data(), ntiles, ntiles);
+    if (rc == RT_OK) rc = TiledUpload(&t->d_first, all_first.data(), ntiles, ntiles);
+    if (rc == RT_OK) rc = TiledUpload<uint32_t>(&t->d_pixels, nullptr, 0, t->first_record[t->nranks]);
+  } else {
+    rc = TiledUpload<uint32_t>(&t->d_pixels, nullptr, 0, t->n_local);
+  }
+  if (rc != RT_OK) return rc;
+  // a rank's rays are its squares stacked: an image one square wide, so that a wave still takes an 8x8 block of pixels
+  t->hint = t->width % t->tile == 0 ? t->tile : 0;
+  return rt_scene_set_param(t->scene, "image_width", t->hint);
+}
+
+uint32_t *TiledMine(const rt_tiled *t) { return t->rank == 0 ? t->d_pixels + t->first_record[0] : t->d_pixels; }
 
 }  // namespace
 
@@ -425,6 +500,126 @@ int rt_gather_scatter(void *comm, int rank, int nranks, int root, int device, co
   if (ntiles == 0) return RT_OK;
   return rt_scatter_tiles(device, gather_dev, rank_first_record[nranks], tile_ids_dev, tile_first_dev, ntiles, tile, width, height, record_bytes,
                           framebuffer_dev, stream);
+}
+
+int rt_tiled_create(rt_scene *scene, void *comm, int rank, int nranks, int width, int height, int tile, const rt_ray_isect *frame_rays_host,
+                    int device, double root_head_start, rt_tiled **out)
+{
+  if (!scene || !frame_rays_host || !out || width <= 0 || height <= 0 || tile <= 0 || nranks <= 0 || rank < 0 || rank >= nranks)
+    return RtFail(RT_ERR_INVALID, "bad sharded frame arguments");
+  if (nranks > 1 && !comm) return RtFail(RT_ERR_INVALID, "a communicator is needed for more than one rank");
+  if (!(root_head_start >= 0.0)) return RtFail(RT_ERR_INVALID, "the head start must be a non-negative number");
+  if (static_cast<uint64_t>(width) * static_cast<uint64_t>(height) > 0x7FFFFFFFull) return RtFail(RT_ERR_INVALID, "image too large");
+  rt_tiled *t = new (std::nothrow) rt_tiled;
+  if (!t) return RtFail(RT_ERR_NOMEM, "out of memory");
+  t->scene = scene; t->comm = comm; t->rank = rank; t->nranks = nranks; t->device = device;
+  t->width = width; t->height = height; t->tile = tile; t->head = root_head_start;
+  const size_t tx = (width + tile - 1) / tile, ty = (height + tile - 1) / tile;
+  int rc = RT_OK;
+  try {
+    t->frame.assign(frame_rays_host, frame_rays_host + static_cast<size_t>(width) * height);
+    t->tile_order.resize(tx * ty);
+    t->first_tile.resize(nranks + 1);
+    t->first_record.resize(nranks + 1);
+  } catch (const std::bad_alloc &) {
+    rc = RtFail(RT_ERR_NOMEM, "out of memory");
+  }
+  // the first deal is round-robin; rt_tiled_redeal deals by measured cost
+  if (rc == RT_OK) rc = rt_shard_plan(width, height, tile, nranks, nullptr, nullptr, nullptr, t->tile_order.data(), t->first_tile.data(), t->first_record.data());
+  if (rc == RT_OK) rc = TiledBuild(t);
+  if (rc != RT_OK) {
+    rt_tiled_destroy(t);
+    return rc;
+  }
+  *out = t;
+  return RT_OK;
+}
+
+void rt_tiled_destroy(rt_tiled *t)
+{
+  if (!t) return;
+  {
+    DeviceScope scope(t->device);
+    if (scope.ok) TiledFreeDevice(t);
+  }
+  delete t;
+}
+
+int rt_tiled_info(const rt_tiled *t, uint64_t info[4])
+{
+  if (!t || !info) return RtFail(RT_ERR_INVALID, "null argument");
+  info[0] = t->n_local;
+  info[1] = t->first_tile[t->rank + 1] - t->first_tile[t->rank];
+  info[2] = t->tile_order.size();
+  info[3] = static_cast<uint64_t>(t->hint);
+  return RT_OK;
+}
+
+int rt_tiled_render(rt_tiled *t, const float cam[16], void *framebuffer_dev, void *stream)
+{
+  if (!t || !cam) return RtFail(RT_ERR_INVALID, "null argument");
+  if (t->rank == 0 && !framebuffer_dev) return RtFail(RT_ERR_INVALID, "the gathering rank needs a framebuffer");
+  uint32_t *mine = TiledMine(t);
+  int rc = rt_trace_pass_bgra8(t->scene, t->d_rays, nullptr, mine, t->n_local, cam, 0u, stream);
+  if (rc != RT_OK) return rc;
+  const bool root = t->rank == 0;
+  return rt_gather_scatter(t->comm, t->rank, t->nranks, 0, t->device, mine, root ? t->d_pixels : nullptr, t->first_record.data(), 4u,
+                           root ? t->d_ids : nullptr, root ? t->d_first : nullptr, root ? t->tile_order.size() : 0u, t->tile, t->width, t->height,
+                           framebuffer_dev, stream);
+}
+
+int rt_tiled_redeal(rt_tiled *t, const float cam[16], size_t *squares_moved)
+{
+  if (!t || !cam) return RtFail(RT_ERR_INVALID, "null argument");
+  const size_t ntiles = t->tile_order.size(), nmy = t->first_tile[t->rank + 1] - t->first_tile[t->rank];
+  std::vector<double> sq(ntiles, 0.0);
+  {
+    DeviceScope scope(t->device);
+    if (!scope.ok) return RtFail(RT_ERR_DEVICE, "hipSetDevice failed");
+    hipError_t he = hipDeviceSynchronize();   // frames in flight use the buffers this call replaces
+    if (he != hipSuccess) return RtFail(RT_ERR_DEVICE, std::string("hipDeviceSynchronize: ") + hipGetErrorString(he));
+    if (t->n_local) {
+      // this rank's rays as the trace step sees them (camera rows dotted with (origin, 1) and (direction, 0)); the costs only
+      // rank the squares, so the host's rounding of these sums need not be the kernel's
+      std::vector<rt_ray_isect> seen = t->rays;
+      for (rt_ray_isect &r : seen) {
+        const float o[4] = {r.origin.x, r.origin.y, r.origin.z, 1.f}, d[4] = {r.direction.x, r.direction.y, r.direction.z, 0.f};
+        float oo[3], dd[3];
+        for (int k = 0; k < 3; ++k) {
+          oo[k] = cam[4 * k] * o[0] + cam[4 * k + 1] * o[1] + cam[4 * k + 2] * o[2] + cam[4 * k + 3] * o[3];
+          dd[k] = cam[4 * k] * d[0] + cam[4 * k + 1] * d[1] + cam[4 * k + 2] * d[2] + cam[4 * k + 3] * d[3];
+        }
+        r.origin.x = oo[0]; r.origin.y = oo[1]; r.origin.z = oo[2];
+        r.direction.x = dd[0]; r.direction.y = dd[1]; r.direction.z = dd[2];
+      }
+      rt_ray_isect *d_seen = nullptr;
+      int rc = TiledUpload(&d_seen, seen.data(), seen.size(), seen.size());
+      size_t nunits = 0;
+      if (rc == RT_OK) rc = rt_scene_unit_costs(t->scene, d_seen, t->n_local, nullptr, 0, &nunits);
+      std::vector<uint32_t> costs(nunits);
+      if (rc == RT_OK) rc = rt_scene_unit_costs(t->scene, d_seen, t->n_local, costs.data(), costs.size(), &nunits);
+      if (d_seen) (void)hipFree(d_seen);
+      if (rc == RT_OK)
+        rc = rt_shard_square_costs(costs.data(), nunits, t->hint, t->n_local, t->tile_order.data() + t->first_tile[t->rank], t->my_first.data(), nmy,
+                                   sq.data(), ntiles);
+      if (rc != RT_OK) return rc;
+    }
+  }
+  int rc = rt_comm_sum_f64(t->comm, t->nranks, t->device, sq.data(), ntiles);
+  if (rc != RT_OK) return rc;
+  std::vector<int> owner_before(ntiles, 0);
+  for (int r = 0; r < t->nranks; ++r)
+    for (uint64_t i = t->first_tile[r]; i < t->first_tile[r + 1]; ++i) owner_before[t->tile_order[i]] = r;
+  std::vector<double> head(t->nranks, 0.0);
+  head[0] = t->nranks > 1 ? t->head : 0.0;
+  rc = rt_shard_plan(t->width, t->height, t->tile, t->nranks, nullptr, sq.data(), head.data(), t->tile_order.data(), t->first_tile.data(),
+                     t->first_record.data());
+  if (rc != RT_OK) return rc;
+  size_t moved = 0;
+  for (int r = 0; r < t->nranks; ++r)
+    for (uint64_t i = t->first_tile[r]; i < t->first_tile[r + 1]; ++i) moved += owner_before[t->tile_order[i]] != r;
+  if (squares_moved) *squares_moved = moved;
+  return TiledBuild(t);
 }
 
 }  // extern "C"
