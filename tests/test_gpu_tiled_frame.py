@@ -73,3 +73,27 @@ def test_tiled_frame_rejects_bad_arguments(rt, gpu):
         frame.render(np.eye(4, dtype=np.float32), None, 0)           # the gathering rank needs a framebuffer
     frame.close()
     scene.close()
+
+
+def test_tiled_frame_of_a_rank_that_does_not_gather(rt, gpu):
+    """Rank 1 of 2 holds its own squares' rays and no framebuffer tables; its re-deal goes through the communicator's sum
+    (here a one-rank communicator, so only its own squares carry a cost) and leaves a consistent object.  Nothing is
+    rendered: the exchange needs the other rank."""
+    W, H, tile = 328, 200, 64
+    mesh = rt.Mesh.load_obj(os.path.join(rt.MODELS_DIR, "bunny.obj"), "tolerant")
+    bvh = rt.BVH(mesh, "fixed")
+    rays = rt.primary_rays(W, H, rt.frame_camera(bvh.root_box, W, H))
+    comm = rt.Comm(rt.Comm.unique_id(), 1, 0, 0)
+    scene = rt.Scene(mesh, bvh, device=0, width=4)
+    frame = rt.TiledFrame(scene, comm, 1, 2, W, H, tile, rays, 0, 0.05)
+    plan = rt.ShardPlan(W, H, tile, 2)
+    info = frame.info()
+    assert info["rays"] == plan.records(1) and info["squares"] == len(plan.tiles[1]) and info["squares_of_frame"] == len(plan.tile_order)
+    assert info["image_width"] == 0                        # 328 is not a multiple of 64: edge squares are narrower
+    moved = frame.redeal(np.eye(4, dtype=np.float32))
+    after = frame.info()
+    assert 0 <= moved <= info["squares_of_frame"] and after["squares_of_frame"] == info["squares_of_frame"]
+    assert 0 <= after["rays"] <= W * H
+    frame.close()
+    scene.close()
+    comm.close()
