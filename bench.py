@@ -44,6 +44,7 @@ import argparse
 import contextlib
 import json
 import os
+import sys
 import threading
 import time
 import types
@@ -1281,6 +1282,23 @@ def main():
                        "seconds": round(cdt, 2), "id_mismatches_vs_gpu": int((gid != oid).sum()),
                        "t_bit_mismatches_vs_gpu": int((gt[hit].view(np.uint32) != ot[hit].view(np.uint32)).sum())}
             del all_rays
+
+        # The N = 1 point of the multi-GPU series: with N > 1 this script times ONE dragon 3840x2160 frame cut into squares
+        # (--workload tiles4k, strong scaling), so the headline run carries the same step on this one GPU, run as a child process
+        # once everything above is done.  Never `value`.
+        if world == 1 and workload == "dragon1080" and not a.no_compare and not a.no_cpu_baseline:
+            import subprocess
+            try:
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "tiles4k", "--steps", "60", "--warmup", "10",
+                                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=150)
+                t4 = json.loads(child.stdout.strip().splitlines()[-1])
+                extra["sharded_4k_frame_on_one_gpu"] = {
+                    "workload": t4["config"]["workload"], "value": t4["value"], "unit": t4["unit"], "ms_per_step": t4["ms_per_step"],
+                    "frames_in_flight": t4.get("frames_in_flight"), "gathered_record": t4.get("gathered_record"),
+                    "rt_tiled_object": t4.get("rt_tiled_object"),
+                    "what": "python bench.py --workload tiles4k on this GPU: the N = 1 point of what --gpus N > 1 measures"}
+            except Exception as e:      # reported, never fatal to the headline line
+                extra["sharded_4k_frame_on_one_gpu"] = {"failed": f"{type(e).__name__}: {e}"[:300]}
 
         if W:
             what = f"{model} {W}x{H} primary rays"
