@@ -548,6 +548,9 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
                 for sc in scene_sets[key]:
                     sc.set_param("image_width", hint)
                     sc.set_param("side_stream", side)
+                    # with several frames in flight the next frame's launch fills a launch's tail; splitting the costliest units of
+                    # the full trace step then only adds waves (measured -5 %); one frame at a time keeps the library's default
+                    sc.set_param("trace_split", 0 if frames_in_flight >= 2 else -1)
             scn = [scene_sets[key][b % len(scene_sets[key])] for b in range(NB)]
         root = me == 0
         if R == world:
@@ -670,7 +673,7 @@ def run_tiles4k(a, rank, world, local, dist, red_dev):
         # -- holds up every stream mapped to the same queue.  How that falls out depends on the process (its other streams, the
         # communication library's), so a few pipelines are timed for a moment on every rank and the one with the best slowest
         # rank is kept, streams, scenes and all.
-        cands = [(4, 1), (3, 1), (3, 0), (2, 0), (4, 0)]
+        cands = [(4, 1), (3, 1), (3, 0), (2, 0), (4, 0), (1, 0)]
         tried = {}
         for c in cands:
             cand = build(a.gather, c[0], c[1])

@@ -1206,8 +1206,9 @@ hipError_t LaunchLayout(const KernelArgs &a, int mode, bool count, uint32_t grid
     if (a.split_units) return LaunchOne<WIDTH, QUANT, kModeIntersect, true, true>(a, grid, block, lds, stream, done);
     return LaunchOne<WIDTH, QUANT, kModeIntersect, true, false>(a, grid, block, lds, stream, done);
   }
+  if (mode == kModeTrace && a.split_units) return LaunchOne<WIDTH, QUANT, kModeTrace, false, true>(a, grid, block, lds, stream, done);
   if (mode == kModeTrace) return LaunchOne<WIDTH, QUANT, kModeTrace, false, false>(a, grid, block, lds, stream, done);
-  if (a.split_units) {   // intersection launches only (capi.hip sets split_units for no other)
+  if (a.split_units) {
     if (mode == kModePrimary) return LaunchOne<WIDTH, QUANT, kModePrimary, false, true>(a, grid, block, lds, stream, done);
     return LaunchOne<WIDTH, QUANT, kModeIntersect, false, true>(a, grid, block, lds, stream, done);
   }

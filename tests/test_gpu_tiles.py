@@ -242,6 +242,7 @@ def test_compact_records_and_8_bit_pixels_written_by_the_trace_kernel(rt, gpu):
             with pytest.raises(rt.RtError):
                 scene.intersect_compact(rays_d.data_ptr(), n, out.data_ptr(), 12)
             # pixels
+            scene.set_param("trace_split", 0)
             rgba = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
             px_want = torch.zeros(n, dtype=torch.int32, device="cuda")
             cam = np.eye(4, dtype=np.float32)
@@ -257,6 +258,16 @@ def test_compact_records_and_8_bit_pixels_written_by_the_trace_kernel(rt, gpu):
             assert torch.equal(recs.view(torch.int32), recs_want.view(torch.int32))
             if model == "cube_mirror_test.obj":
                 assert len(torch.unique(px_want)) > 2
+            # the full trace step with its costliest units split over cooperative quarter waves (always / by the launch's size)
+            for ts in (1, -1):
+                scene.set_param("trace_split", ts)
+                for rep in range(4):
+                    px.fill_(-7)
+                    recs.zero_()
+                    scene.trace_pass_bgra8(rays_d.data_ptr(), recs.data_ptr(), px.data_ptr(), n, cam, 0)
+                    torch.cuda.synchronize()
+                    assert torch.equal(px[:n], px_want) and bool((px[n:] == -7).all()), (model, ts, rep)
+                    assert torch.equal(recs.view(torch.int32), recs_want.view(torch.int32)), (model, ts, rep)
             # the lane-refilling kernel (linear ray set, no image hint)
             scene.set_param("image_width", 0)
             scene.set_param("refill", 40)
