@@ -158,7 +158,7 @@ int rt_scene_records(const rt_scene *s, int which, void *out, size_t capacity, s
  *   "trace_split"    -1 (default), 0 or 1: whether the full trace step (rt_trace_pass*) splits its costliest units as well.
  *                    A small launch -- one pass of a 1080p frame, one rank's share of a sharded frame -- is mostly tail and
  *                    gains 3-40 % from it; a launch that fills the GPU many times over, or one of several frames in flight,
- *                    only pays for the extra waves (-5 %).  -1 splits launches of at most 65 536 work units (4 Mi rays).
+ *                    only pays for the extra waves (-5 %).  -1 splits launches of at most 32 768 work units (2 Mi rays: a 1080p frame).
  *   "split_coop"     1 (default): those quarter waves work four lanes per ray -- one child box of the ray's node or one
  *                    triangle of its leaf per lane, the quad agreeing on the nearest child / closest hit -- on the
  *                    four-wide quantized layout, when the tree's worst-case stack fits the LDS columns of a quad.

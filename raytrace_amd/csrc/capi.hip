@@ -76,7 +76,7 @@ int Upload(T **dst, const void *src, size_t bytes)
 }
 
 constexpr uint32_t kFeedbackMaxRays = 1u << 30;  // single-launch calls only
-constexpr uint32_t kTraceSplitMaxUnits = 65536;   // full-trace launches of up to this many work units (4 Mi rays) split their costliest units by default
+constexpr uint32_t kTraceSplitMaxUnits = 32768;   // full-trace launches of up to this many work units (2 Mi rays) split their costliest units by default
 constexpr int kStatShards = 64;          // instrumented build: counter shards, 16 uint64 (one line) each
 constexpr uint32_t kCursorSlots = 64, kCursorStride = 32;   // persistent launches: cursor words, one line apart
 
