@@ -155,10 +155,14 @@ int rt_scene_records(const rt_scene *s, int which, void *out, size_t capacity, s
  *                    long as the traversal steps its rays need between them; this many units at the head of the
  *                    costliest-first order are traced by four waves each (4x4 pixels or 16 records per wave) instead
  *                    of one.  Capped at the launch's unit count; 0 = never.
+ *   "split_max_units" 0..16777216 (default 40960): launches of more work units than this are not split.  A launch is mostly
+ *                    tail while it is small -- a 1080p frame (32 400 units) gains 3-14 %, a rank's share of a sharded frame up
+ *                    to 40 % -- and from about 2560x1440 (57 600 units) on the extra waves cost more than the tail (-1..-4 %).
  *   "trace_split"    -1 (default), 0 or 1: whether the full trace step (rt_trace_pass*) splits its costliest units as well.
  *                    A small launch -- one pass of a 1080p frame, one rank's share of a sharded frame -- is mostly tail and
  *                    gains 3-40 % from it; a launch that fills the GPU many times over, or one of several frames in flight,
- *                    only pays for the extra waves (-5 %).  -1 splits launches of at most 32 768 work units (2 Mi rays: a 1080p frame).
+ *                    only pays for the extra waves (-5 %).  -1 splits by size like the intersection launches ("split_max_units"),
+ *                    1 whatever the size, 0 never.
  *   "split_coop"     1 (default): those quarter waves work four lanes per ray -- one child box of the ray's node or one
  *                    triangle of its leaf per lane, the quad agreeing on the nearest child / closest hit -- on the
  *                    four-wide quantized layout, when the tree's worst-case stack fits the LDS columns of a quad.

@@ -76,7 +76,6 @@ int Upload(T **dst, const void *src, size_t bytes)
 }
 
 constexpr uint32_t kFeedbackMaxRays = 1u << 30;  // single-launch calls only
-constexpr uint32_t kTraceSplitMaxUnits = 32768;   // full-trace launches of up to this many work units (2 Mi rays) split their costliest units by default
 constexpr int kStatShards = 64;          // instrumented build: counter shards, 16 uint64 (one line) each
 constexpr uint32_t kCursorSlots = 64, kCursorStride = 32;   // persistent launches: cursor words, one line apart
 
@@ -169,7 +168,8 @@ struct rt_scene {
   mutable size_t fb_left_used = 0;
   int waves_per_cu = 0;          // optional resident-wave cap per CU, held through the LDS stack size (0 = none)
   int refill = 0;                // > 0: linear ray sets with compact hits go to the lane-refilling kernel; idle lanes that trigger a refill
-  int trace_split = -1;          // the full trace step splits its costliest units too: 1 always, 0 never, -1 for launches of at most kTraceSplitMaxUnits units
+  int split_max_units = 40960;   // launches of more work units than this are not split: they fill the chip many times over and only pay for the extra waves
+  int trace_split = -1;          // the full trace step: -1 splits like the intersection launches (by size), 1 whatever the size, 0 never
   int split_coop = 1;            // the quarter waves of split units work four lanes per ray (one child box / one triangle per lane)
   int split_units = 128;         // with a cost-sorted order: this many units, the costliest, are traced by four waves each
   int prio_permille = 0;         // with a cost-sorted order: this share (1/1000) of the leading dispatch slots runs at raised priority
@@ -420,7 +420,10 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     // The full trace step splits only where it pays: a small launch (a 1080p pass, a rank's share of a frame) is mostly tail
     // and gains 3-40 %; a launch that fills the chip many times over, or one of several frames in flight, only pays for the
     // extra waves (-5 %), so callers who pipeline frames switch it off ("trace_split").
-    const bool may_split = mode != rt::kModeTrace || s->trace_split == 1 || (s->trace_split < 0 && a.ntasks <= kTraceSplitMaxUnits);
+    // Measured by launch size (dragon, one launch at a time): 32 400 units (1080p) +3..14 %, a rank's share of a sharded frame
+    // up to +40 %; 57 600 units (2560x1440) and more -1..-4 %.
+    const bool small = a.ntasks <= static_cast<uint32_t>(s->split_max_units);
+    const bool may_split = mode != rt::kModeTrace ? small : (s->trace_split == 1 || (s->trace_split < 0 && small));
     if (a.order && !a.cursor && may_split) {
       // The launch cannot end before its longest wave does, and a wave's length is the number of traversal steps its 64 rays
       // need between them.  The costliest units are therefore cut into four (16 rays per wave, 4x4 pixels or 16 records):
@@ -442,7 +445,7 @@ int Enqueue(const rt_scene *s, rt::KernelArgs &a, int mode, bool count, hipStrea
     if (!s->fb_sorted[newest]) return Fail(RT_ERR_INVALID, "internal: no cost-sorted order yet");
     RT_HIP(hipStreamWaitEvent(stream, s->ev_sort[newest], 0));
     a.order = s->d_fb_order[newest];
-    a.split_units = std::min(static_cast<uint32_t>(s->split_units), a.ntasks);   // ... split like the launches it stands for
+    a.split_units = a.ntasks <= static_cast<uint32_t>(s->split_max_units) ? std::min(static_cast<uint32_t>(s->split_units), a.ntasks) : 0u;   // ... split like the launches it stands for
     grid = (a.ntasks + 3u * a.split_units + wpb - 1u) / wpb;
     a.coop = CoopFits(s, a) ? 1u : 0u;
   }
@@ -877,6 +880,9 @@ int rt_scene_set_param(rt_scene *s, const char *key, int value)
   } else if (k == "split_units") {
     if (value < 0 || value > 65536) return Fail(RT_ERR_INVALID, "split_units must be in 0..65536");
     s->split_units = value;
+  } else if (k == "split_max_units") {
+    if (value < 0 || value > (1 << 24)) return Fail(RT_ERR_INVALID, "split_max_units must be in 0..16777216");
+    s->split_max_units = value;
   } else if (k == "trace_split") {
     if (value < -1 || value > 1) return Fail(RT_ERR_INVALID, "trace_split must be -1, 0 or 1");
     s->trace_split = value;

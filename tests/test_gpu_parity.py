@@ -632,6 +632,8 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
         dict(image_width=W, leaf_pct=37, block_threads=128, width=4),
         dict(image_width=W, quantized=0, feedback=1, width=4),
         dict(image_width=W, feedback=1, split_units=0, width=4),
+        dict(image_width=W, feedback=1, split_max_units=100, width=4),      # 3600 units > 100: the launch is not split
+        dict(image_width=W, feedback=1, split_max_units=3600, width=4),     # exactly at the limit: split
         dict(image_width=W, feedback=1, split_units=7, width=4),
         dict(image_width=W, feedback=1, split_units=65536, block_threads=256, width=4),   # capped: every unit is split
         dict(image_width=0, feedback=1, split_units=501, block_threads=128),
@@ -648,7 +650,7 @@ def test_schedule_knobs_never_change_a_result(rt, oracle, gpu):
     ]
     defaults = dict(width=2, quantized=1, block_threads=64, image_width=0, leaf_pct=50, persistent=0, split_units=32, split_coop=1,
                     feedback_period=4, persistent_waves=24, lds_stack=10, centre_first=1, feedback=0, feedback_radius=1, feedback_share=96,
-                    side_stream=0)
+                    side_stream=0, split_max_units=40960)
     for cfg in settings:
         for k, v in {**defaults, **cfg}.items():
             scene.set_param(k, v)

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytrace_amd as rt  # noqa: E402
 
 WORK = {"dragon1080": ("dragon.obj", 1920, 1080), "bunny1080": ("bunny.obj", 1920, 1080),
-        "dragon4k": ("dragon.obj", 3840, 2160), "ao": ("bunny_big.obj", 0, 0), "teapot1080": ("teapot.obj", 1920, 1080)}
+        "dragon4k": ("dragon.obj", 3840, 2160), "dragon1440": ("dragon.obj", 2560, 1440), "dragon1620": ("dragon.obj", 2880, 1620), "ao": ("bunny_big.obj", 0, 0), "teapot1080": ("teapot.obj", 1920, 1080)}
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="dragon1080")
 ap.add_argument("--rounds", type=int, default=7)
