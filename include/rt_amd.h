@@ -378,7 +378,7 @@ int rt_gather_scatter(void *comm, int rank, int nranks, int root, int device, co
  * device per frame) for a job of one process per GPU.  rt_tiled_create takes the frame's ray table (width x height records,
  * host memory, copied: e.g. rt_primary_rays, the reference's camera table), deals the squares round-robin, uploads this
  * rank's rays (its squares one after the other) and sets the scene's "image_width" to the squares' width -- give the object
- * a scene of its own.  rt_tiled_render enqueues one frame on `stream` of every rank: the full trace step over this rank's
+ * a scene of its own (`device` is that scene's device).  rt_tiled_render enqueues one frame on `stream` of every rank: the full trace step over this rank's
  * rays (rt_trace_pass_bgra8, operation 0 with `cam`) and rt_gather_scatter; rank 0's framebuffer_dev (width x height 8-bit
  * BGRA pixels, row-major; ignored on the other ranks) holds the frame when the stream gets there.  One frame at a time
  * per object (frames on different streams would share its buffers): for frames in flight make one object, with a scene of
