@@ -223,3 +223,14 @@ def test_headless_driver_frame_matches_the_library_path(rt, gpu, tmp_path):
     want = np.stack([q[..., 2], q[..., 1], q[..., 0], np.full((H, W), 255, np.uint8)], axis=-1)
     assert np.abs(got.astype(int) - want.astype(int)).max() <= 1            # float blend order may differ in the last bit
     assert (got[..., :3].sum(axis=-1) > 0).mean() > 0.02                      # the frame shows something
+    # the primary pass alone, plainly and through the sharded-frame object (one rank, 32 x 32 squares): the same file
+    frames = []
+    for extra in ([], ["--tiled", "32"]):
+        path = str(tmp_path / f"primary{len(extra)}.bmp")
+        r = subprocess.run([exe, "--model", model, "--width", str(W), "--height", str(H), "--loader", "reference", "--bvh", "sah",
+                            "--bounces", "0", "--device", str(gpu), "--out", path] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        frames.append(open(path, "rb").read())
+    assert frames[0] == frames[1]
+    lit = np.frombuffer(frames[0][58:], np.uint8).reshape(H, W, 4)[..., :3].any(axis=-1)
+    assert 0.02 < lit.mean() < 0.98                                          # a silhouette: a misplaced square would show

@@ -6,7 +6,10 @@
 // downloads the 8-bit frame and writes a BMP instead of presenting a window.
 //
 //   rt_headless [--model PATH] [--width W] [--height H] [--loader reference|tolerant]
-//               [--bvh reference|fixed|sah] [--wide 2|4] [--bounces N] [--device D] [--out FILE.bmp]
+//               [--bvh reference|fixed|sah] [--wide 2|4] [--bounces N] [--device D] [--out FILE.bmp] [--tiled T]
+// --tiled T (with --bounces 0): the frame goes through the sharded-frame object instead (rt_tiled_create / _redeal / _render
+// with one rank: the image cut into T x T squares, traced square by square, scattered into the framebuffer on the device) --
+// the call sequence of a job of one process per GPU, and the same bytes in the BMP.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -38,7 +41,7 @@
 int main(int argc, char **argv)
 {
   std::string model = "assets/models/cube_mirror_test.obj", out = "frame.bmp";
-  int W = 560, H = 560, wide = 2, bounces = 1, device = 0;
+  int W = 560, H = 560, wide = 2, bounces = 1, device = 0, tiled = 0;
   unsigned loader = RT_LOADER_TOLERANT, bvhmode = RT_BVH_FIXED;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -55,9 +58,10 @@ int main(int argc, char **argv)
     else if (a == "--bounces") bounces = std::atoi(next());
     else if (a == "--device") device = std::atoi(next());
     else if (a == "--out") out = next();
+    else if (a == "--tiled") tiled = std::atoi(next());
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }
-  if (W <= 0 || H <= 0 || bounces < 0 || (wide != 2 && wide != 4)) { std::fprintf(stderr, "bad arguments\n"); return 2; }
+  if (W <= 0 || H <= 0 || bounces < 0 || (wide != 2 && wide != 4) || tiled < 0 || (tiled > 0 && bounces != 0)) { std::fprintf(stderr, "bad arguments\n"); return 2; }
 
   rt_mesh *mesh = nullptr;
   CHECK(rt_mesh_load_obj(model.c_str(), loader, &mesh));
@@ -96,7 +100,16 @@ int main(int argc, char **argv)
   const float identity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   auto t0 = std::chrono::steady_clock::now();
   void *src = d_cam, *dst = d_a;
-  for (int pass = 0; pass <= bounces; ++pass) {
+  if (tiled > 0) {
+    rt_tiled *frame = nullptr;
+    size_t moved = 0;
+    CHECK(rt_tiled_create(scene, /*comm*/nullptr, /*rank*/0, /*nranks*/1, W, H, tiled, rays.data(), device, 0.0, &frame));
+    CHECK(rt_tiled_redeal(frame, identity, &moved));      // with one rank every square stays; the call is what a moving camera repeats
+    CHECK(rt_tiled_render(frame, identity, d_bgra, nullptr));
+    HIPCHECK(hipDeviceSynchronize());
+    rt_tiled_destroy(frame);
+  }
+  for (int pass = 0; pass <= bounces && tiled == 0; ++pass) {
     CHECK(rt_trace_pass(scene, src, dst, pass == 0 ? d_frame : d_layer, n, identity, pass == 0 ? 0u : 1u, nullptr));
     const bool last = pass == bounces;
     if (pass > 0) CHECK(rt_composite_layers(device, d_frame, d_layer, n, d_frame, last ? d_bgra : nullptr, nullptr));
